@@ -1,0 +1,159 @@
+/*
+ * mgcn_hip.h — C ABI of libmgcn_hip.so: the MI355X (gfx950) implementation of the M-GCN hot path.
+ *
+ * The reference (weilonghu/KGC-GCN) has no FFI of its own: the hot path is Python calling torch /
+ * torch_geometric / torch_scatter tensor ops. Each entry point below therefore replaces a span of
+ * reference Python, cited as file:line relative to the reference root. The Python host side
+ * (kgc-gcn_amd/_native.py) binds these with ctypes; INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every pointer named *_dev is a BORROWED device pointer (owned by the caller, e.g. a torch
+ *     tensor that outlives the call); pointers named *_host are host memory;
+ *   - all device work is enqueued asynchronously on `stream`; nothing here allocates, frees or
+ *     synchronises the device, so every call may be captured into a hipGraph;
+ *   - return value 0 = MGCN_OK; otherwise an MGCN_E* code, and mgcn_last_error() returns a
+ *     thread-local, human-readable message;
+ *   - no global mutable state besides that thread-local error string; re-entrant per device;
+ *   - matrices are row-major f32, indices int32 on the device, int64 on the host side of the feeder.
+ */
+#ifndef MGCN_HIP_H
+#define MGCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGCN_ABI_VERSION 1
+
+enum {
+  MGCN_OK = 0,
+  MGCN_EINVAL = 1,  /* bad argument: null pointer, negative size, index out of range, misalignment */
+  MGCN_ELAUNCH = 2, /* hipGetLastError() after a launch */
+  MGCN_EUNSUPPORTED = 3
+};
+
+/* One CSR slot = one directed edge in destination order. 16 bytes, read as one dwordx4. */
+typedef struct mgcn_edge_rec {
+  int32_t src;  /* source node (row of the layer input that is gathered)                          */
+  int32_t type; /* row of the relation table [2R+1, D]                                             */
+  float norm;   /* deg^-1/2[src] * deg^-1/2[dst], degrees counted by SOURCE within the half (Q2)  */
+  int32_t eid;  /* reference edge id (row of the per-edge table in reference order)               */
+} mgcn_edge_rec;
+
+int mgcn_abi_version(void);
+const char *mgcn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) Feeder — host side. Replaces data_loader.py:132-157 (`_build_graph`: the bi-directional edge
+ * list) as consumed by model.py:88-97 (split into the in-half [0,E) and out-half [E,2E), degree
+ * norms per half, `compute_norm` model.py:72-80, hoisted out of the step because the graph is
+ * static).
+ *   edge_index_host [2, 2E] int64 (row 0 = src, row 1 = dst), edge_type_host [2E] int64.
+ * Outputs (host, caller-allocated):
+ *   rowptr_host [2, N+1] int32   per half, CSR by DESTINATION, positions relative to the half;
+ *   rec_host    [2E]             slot h*E + p = p-th edge of half h in (dst, edge id) order — the
+ *                                order a CPU scatter-add visits them;
+ *   perm_host   [2E] int64       slot -> reference edge id (to lay the per-edge table out in slot
+ *                                order once, so the kernel streams it);
+ * Optional outputs for the backward pass (all three NULL, or all three non-NULL plus the type pair):
+ *   slot_dst_host [2E] int32     destination node of each slot;
+ *   srcptr_host [2, N+1] int32, srcslots_host [2E] int32
+ *                                per half, the slots (global slot ids, ascending) grouped by SOURCE;
+ *   typeptr_host [num_rel_rows+1] int32, typeslots_host [2E] int32
+ *                                all slots (ascending) grouped by relation-table row.
+ * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows).
+ */
+int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_rel_rows,
+                        const int64_t *edge_index_host, const int64_t *edge_type_host,
+                        int32_t *rowptr_host, mgcn_edge_rec *rec_host, int64_t *perm_host,
+                        int32_t *slot_dst_host, int32_t *srcptr_host, int32_t *srcslots_host,
+                        int32_t *typeptr_host, int32_t *typeslots_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) Aggregation forward. Replaces the gather / message / scatter-add of the three `propagate`
+ * calls, model.py:99-101 + 111-118 (+ the identity gathers model.py:29-30), with the weight
+ * multiply moved after the sum:
+ *   A[n, 0:D)   = sum over in-half  slots p of n:  norm_p * ((x[src_p] * rel[type_p]) * ee_p)
+ *   A[n, D:2D)  = same over the out-half
+ *   A[n, 2D:3D) = (x[n] * rel[num_rel_rows-1]) * loop_edge            (self loop, no norm)
+ * Slots of one destination are summed in slot order by one lane group: no atomics, bitwise
+ * reproducible. `ee_dev` is the per-edge table: in SLOT order if ee_in_slot_order != 0 (streamed),
+ * else in reference edge-id order (gathered through rec.eid); NULL = no per-edge factor.
+ *   x_dev [N, D] (ldx floats between rows), rel_dev [num_rel_rows, D], loop_edge_dev [D] or NULL
+ *   (then the third block is not written and A needs only 2D columns), a_dev [N, lda].
+ */
+int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
+                       const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
+                       int64_t ldx, const float *rel_dev, const float *ee_dev, int32_t ee_in_slot_order,
+                       const float *loop_edge_dev, float *a_dev, int64_t lda, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) Aggregation backward (autograd through (2); driven by main.py:66). Given g = dL/dA [N, lda]
+ * (first 2D columns used):
+ *   gx[s]   = sum over slots p with src_p = s of norm_p * g[dst_p, half] * rel[type_p] * ee_p
+ *   gee[p]  = norm_p * g[dst_p, half] * x[src_p] * rel[type_p]                 (slot order)
+ *   grel[t] = sum over slots p with type_p = t of norm_p * g[dst_p, half] * x[src_p] * ee_p
+ * gx walks srcptr/srcslots (slots grouped by source), grel walks typeptr/typeslots (slots grouped by
+ * relation row, long lists cut into fixed chunks whose partial sums are added in chunk order); all
+ * from mgcn_csr_build_host. Segment sums in a fixed order: no float atomics, bitwise reproducible.
+ * Any of gx/gee/grel may be NULL. gx [N, D], gee [2E, D] in slot order, grel [num_rel_rows, D].
+ */
+int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
+                       const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev, const int32_t *srcptr_dev,
+                       const int32_t *srcslots_dev, const int32_t *typeptr_dev, const int32_t *typeslots_dev,
+                       const float *x_dev, int64_t ldx, const float *rel_dev, const float *ee_dev,
+                       const float *g_dev, int64_t ldg, float *gx_dev, float *gee_dev, float *grel_dev,
+                       float *workspace_dev, size_t workspace_bytes, void *stream);
+size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows); /* bytes, for grel */
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) Dense step + epilogue (f32 MFMA, exact f32). Replaces model.py:116 (moved after the sum) and
+ * model.py:103-106 in eval mode:
+ *   out = tanh( BN_eval( (A[:,0:D) W_in + A[:,D:2D) W_out + A[:,2D:3D) W_loop) / 3 + bias ) )
+ * BN_eval(v) = (v - mean) / sqrt(var + eps) * gamma + beta. bias_dev may be NULL.
+ */
+int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, const float *a_dev, int64_t lda,
+                           const float *w_in_dev, const float *w_out_dev, const float *w_loop_dev,
+                           const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev,
+                           const float *bn_gamma_dev, const float *bn_beta_dev, float bn_eps,
+                           float *out_dev, int64_t ldo, void *stream);
+
+/* Plain C[M,N] = A[M,K] @ B[K,N] on the same f32 MFMA kernel (model.py:107, the relation projection). */
+int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t lda, const float *b_dev,
+                    int64_t ldb, float *c_dev, int64_t ldc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (5) Full-graph scoring and filtered ranking. Replaces model.py:177-179 and main.py:122-126.
+ *   score[b, n] = sigmoid( x[b,:] . ent[n,:] + bias[n] ),  x [B, O], ent [n_local, O].
+ * mgcn_score_fwd materialises score [B, n_local] (training / the drop-in forward()).
+ * mgcn_score_target computes target[b] = score[b, obj[b]] for the queries whose obj lies in
+ *   [ent_row0, ent_row0 + n_local) with the SAME arithmetic as the tile kernels (others untouched).
+ * mgcn_score_rank never materialises the scores: for every b it adds to counts[b, 0..2]
+ *   gt   = #{n != obj[b], not filtered : score[b,n] >  target[b]}
+ *   tl   = #{n != obj[b], not filtered, n <  obj[b] : score[b,n] == target[b]}   (ties_lower)
+ *   ties = #{n != obj[b], not filtered : score[b,n] == target[b]}
+ * where n is filtered iff label[b, n] (f32, row stride ldl, the shard's own columns) is >= 1.
+ * counts [B,3] int64 must be zeroed by the caller; integer atomics => order independent.
+ * rank = 1 + gt (+ tl under the stable tie rule). With an entity shard per GPU the caller sums
+ * counts over ranks (RCCL all-reduce); `ent_row0` is the shard's first global entity id.
+ */
+int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx,
+                   const float *ent_dev, int64_t lde, const float *bias_dev, float *score_dev, int64_t lds,
+                   void *stream);
+int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                      int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                      const int64_t *obj_dev, float *target_dev, void *stream);
+int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                    int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                    const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                    int64_t *counts_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGCN_HIP_H */

@@ -1,0 +1,246 @@
+"""ctypes binding of libmgcn_hip.so (include/mgcn_hip.h) — the only way the package reaches the GPU.
+
+There is deliberately NO fallback: if the library is missing or a tensor is not resident on a GPU the
+call raises. torch is used here for device memory and the current HIP stream only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+_i32, _i64, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+_ptr = ctypes.c_void_p
+
+_SIGNATURES = {
+    'mgcn_abi_version': (ctypes.c_int, []),
+    'mgcn_last_error': (ctypes.c_char_p, []),
+    'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64] + [_ptr] * 10),
+    'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32,
+                                          _ptr, _ptr, _i64, _ptr]),
+    'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _i64,
+                                          _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
+    'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 8 + [_f32, _ptr, _i64, _ptr]),
+    'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
+    'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
+    'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
+    'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
+                                       _ptr, _ptr]),
+}
+
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError = symbol missing from the build
+            fn.restype, fn.argtypes = res, args
+        if handle.mgcn_abi_version() != ABI_VERSION:
+            raise NativeError('libmgcn_hip.so ABI %d, binding expects %d' % (handle.mgcn_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise NativeError('%s failed (%d): %s' % (what, rc, lib().mgcn_last_error().decode()))
+
+
+def _dev(t, dtype, what, allow_none=False):
+    """Borrowed device pointer of tensor `t` (last dimension contiguous)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise NativeError('%s: tensor required' % what)
+    if not t.is_cuda:
+        raise NativeError('%s must live on a GPU (got %s): the M-GCN hot path has no CPU fallback' % (what, t.device))
+    if t.dtype != dtype:
+        raise NativeError('%s: dtype %s, expected %s' % (what, t.dtype, dtype))
+    if t.dim() > 0 and t.numel() > 0 and t.stride(-1) != 1:
+        raise NativeError('%s: last dimension must be contiguous' % what)
+    return t.data_ptr()
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 and t.size(0) > 1 else t.size(-1)
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _same_device(*ts):
+    devs = {t.device for t in ts if t is not None}
+    if len(devs) > 1:
+        raise NativeError('tensors on different devices: %s' % sorted(map(str, devs)))
+
+
+# ------------------------------------------------------------------------------------------------
+def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward=True):
+    """(1) Feeder. edge_index [2, 2E] int64, edge_type [2E] int64 (any device; copied to host).
+    Returns a dict of HOST tensors (see mgcn_csr_build_host)."""
+    ei = edge_index.detach().to('cpu', torch.int64).contiguous()
+    et = edge_type.detach().to('cpu', torch.int64).contiguous()
+    if ei.dim() != 2 or ei.size(0) != 2 or ei.size(1) % 2 or et.numel() != ei.size(1):
+        raise NativeError('csr_build: edge_index must be [2, 2E] and edge_type [2E]')
+    E2, E, N = ei.size(1), ei.size(1) // 2, int(num_nodes)
+    out = dict(rowptr=torch.empty((2, N + 1), dtype=torch.int32), rec=torch.empty((E2, 4), dtype=torch.int32),
+               perm=torch.empty(E2, dtype=torch.int64))
+    if with_backward:
+        out.update(slot_dst=torch.empty(E2, dtype=torch.int32), srcptr=torch.empty((2, N + 1), dtype=torch.int32),
+                   srcslots=torch.empty(E2, dtype=torch.int32),
+                   typeptr=torch.empty(num_rel_rows + 1, dtype=torch.int32),
+                   typeslots=torch.empty(E2, dtype=torch.int32))
+    p = lambda k: out[k].data_ptr() if k in out else None
+    _check(lib().mgcn_csr_build_host(N, E, int(num_rel_rows), ei.data_ptr(), et.data_ptr(), p('rowptr'), p('rec'),
+                                     p('perm'), p('slot_dst'), p('srcptr'), p('srcslots'), p('typeptr'),
+                                     p('typeslots')), 'mgcn_csr_build_host')
+    return out
+
+
+def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out):
+    """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR."""
+    N, E, D = csr.num_nodes, csr.num_edges_half, x.size(1)
+    _same_device(csr.rowptr, x, rel, ee, loop_edge, out)
+    if x.size(0) != N or rel.size(0) != csr.num_rel_rows or rel.size(1) != D:
+        raise NativeError('aggregate_fwd: x %s / rel %s do not match graph (N=%d, rel rows=%d)'
+                          % (tuple(x.shape), tuple(rel.shape), N, csr.num_rel_rows))
+    if ee is not None and tuple(ee.shape) != (2 * E, D):
+        raise NativeError('aggregate_fwd: per-edge table %s, expected (%d, %d)' % (tuple(ee.shape), 2 * E, D))
+    if not rel.is_contiguous() or (ee is not None and not ee.is_contiguous()):
+        raise NativeError('aggregate_fwd: relation and per-edge tables must be contiguous')
+    modes = 3 if loop_edge is not None else 2
+    if loop_edge is not None and loop_edge.numel() != D:
+        raise NativeError('aggregate_fwd: loop_edge must have %d elements' % D)
+    if out.size(0) != N or out.size(1) < modes * D:
+        raise NativeError('aggregate_fwd: out %s too small for (%d, %d)' % (tuple(out.shape), N, modes * D))
+    _check(lib().mgcn_aggregate_fwd(
+        N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
+        _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'),
+        _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
+        _dev(out, torch.float32, 'out'), _ld(out), _stream(x)), 'mgcn_aggregate_fwd')
+    return out
+
+
+def aggregate_bwd(csr, x, rel, ee, g, want_gx=True, want_gee=True, want_grel=True):
+    """(3) Gradients of aggregate_fwd's first 2D columns w.r.t. x, the per-edge table (slot order) and rel."""
+    N, E, D = csr.num_nodes, csr.num_edges_half, x.size(1)
+    _same_device(csr.rowptr, x, rel, ee, g)
+    if not csr.has_backward:
+        raise NativeError('aggregate_bwd: graph was prepared without the backward indices')
+    if g.size(0) != N or g.size(1) < 2 * D:
+        raise NativeError('aggregate_bwd: g %s too small' % (tuple(g.shape),))
+    if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows, D) or not rel.is_contiguous():
+        raise NativeError('aggregate_bwd: x / rel do not match the graph')
+    if ee is not None and (tuple(ee.shape) != (2 * E, D) or not ee.is_contiguous()):
+        raise NativeError('aggregate_bwd: per-edge table must be contiguous (%d, %d) in slot order' % (2 * E, D))
+    gx = torch.empty((N, D), dtype=torch.float32, device=x.device) if want_gx else None
+    gee = torch.empty((2 * E, D), dtype=torch.float32, device=x.device) if (want_gee and ee is not None) else None
+    grel = torch.empty((csr.num_rel_rows, D), dtype=torch.float32, device=x.device) if want_grel else None
+    ws_bytes = lib().mgcn_aggregate_bwd_workspace(E, D, csr.num_rel_rows) if want_grel else 0
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device) if want_grel else None
+    _check(lib().mgcn_aggregate_bwd(
+        N, E, D, csr.num_rel_rows, _dev(csr.rec, torch.int32, 'rec'), _dev(csr.slot_dst, torch.int32, 'slot_dst'),
+        _dev(csr.srcptr, torch.int32, 'srcptr'), _dev(csr.srcslots, torch.int32, 'srcslots'),
+        _dev(csr.typeptr, torch.int32, 'typeptr'), _dev(csr.typeslots, torch.int32, 'typeslots'),
+        _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(ee, torch.float32, 'ee', True),
+        _dev(g, torch.float32, 'g'), _ld(g), _dev(gx, torch.float32, 'gx', True), _dev(gee, torch.float32, 'gee', True),
+        _dev(grel, torch.float32, 'grel', True), _dev(ws, torch.float32, 'ws', True), ws_bytes, _stream(x)),
+        'mgcn_aggregate_bwd')
+    return gx, gee, grel
+
+
+def dense_bn_tanh_fwd(a, w_in, w_out, w_loop, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, out):
+    """(4) out = tanh(BN_eval((A [W_in; W_out; W_loop]) / 3 + bias))."""
+    N, D, O = a.size(0), w_in.size(0), w_in.size(1)
+    _same_device(a, w_in, w_out, w_loop, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
+    for w in (w_in, w_out, w_loop):
+        if tuple(w.shape) != (D, O) or not w.is_contiguous():
+            raise NativeError('dense_bn_tanh_fwd: weights must be contiguous (%d, %d)' % (D, O))
+    for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
+        if v.numel() != O:
+            raise NativeError('dense_bn_tanh_fwd: per-column vectors must have %d elements' % O)
+    if a.size(1) < 3 * D or tuple(out.shape) != (N, O):
+        raise NativeError('dense_bn_tanh_fwd: a %s / out %s do not match' % (tuple(a.shape), tuple(out.shape)))
+    _check(lib().mgcn_dense_bn_tanh_fwd(
+        N, D, O, _dev(a, torch.float32, 'a'), _ld(a), _dev(w_in, torch.float32, 'w_in'),
+        _dev(w_out, torch.float32, 'w_out'), _dev(w_loop, torch.float32, 'w_loop'), _dev(bias, torch.float32, 'bias', True),
+        _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
+        _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
+        _dev(out, torch.float32, 'out'), _ld(out), _stream(a)), 'mgcn_dense_bn_tanh_fwd')
+    return out
+
+
+def matmul(a, b):
+    """C = A @ B on the f32 MFMA tile kernel."""
+    _same_device(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.size(1) != b.size(0):
+        raise NativeError('matmul: shapes %s @ %s' % (tuple(a.shape), tuple(b.shape)))
+    c = torch.empty((a.size(0), b.size(1)), dtype=torch.float32, device=a.device)
+    _check(lib().mgcn_matmul_f32(a.size(0), a.size(1), b.size(1), _dev(a, torch.float32, 'a'), _ld(a),
+                                 _dev(b, torch.float32, 'b'), _ld(b), _dev(c, torch.float32, 'c'), _ld(c), _stream(a)),
+           'mgcn_matmul_f32')
+    return c
+
+
+def _score_args(x, ent, bias):
+    _same_device(x, ent, bias)
+    if x.dim() != 2 or ent.dim() != 2 or x.size(1) != ent.size(1) or bias.numel() != ent.size(0):
+        raise NativeError('score: x %s, ent %s, bias %s do not match' % (tuple(x.shape), tuple(ent.shape), tuple(bias.shape)))
+    return x.size(0), ent.size(0), x.size(1)
+
+
+def score_fwd(x, ent, bias):
+    """(5) score [B, n_local] = sigmoid(x @ ent^T + bias)."""
+    B, n, O = _score_args(x, ent, bias)
+    out = torch.empty((B, n), dtype=torch.float32, device=x.device)
+    _check(lib().mgcn_score_fwd(B, n, O, _dev(x, torch.float32, 'x'), _ld(x), _dev(ent, torch.float32, 'ent'), _ld(ent),
+                                _dev(bias, torch.float32, 'bias'), _dev(out, torch.float32, 'score'), _ld(out),
+                                _stream(x)), 'mgcn_score_fwd')
+    return out
+
+
+def score_target(x, ent, bias, obj, ent_row0=0, out=None):
+    """target[b] = score[b, obj[b]] for the queries whose obj is a row of this shard (others keep `out`)."""
+    B, n, O = _score_args(x, ent, bias)
+    if obj.numel() != B:
+        raise NativeError('score_target: obj must have %d elements' % B)
+    if out is None:
+        out = torch.zeros(B, dtype=torch.float32, device=x.device)
+    _check(lib().mgcn_score_target(B, n, int(ent_row0), O, _dev(x, torch.float32, 'x'), _ld(x),
+                                   _dev(ent, torch.float32, 'ent'), _ld(ent), _dev(bias, torch.float32, 'bias'),
+                                   _dev(obj, torch.int64, 'obj'), _dev(out, torch.float32, 'target'), _stream(x)),
+           'mgcn_score_target')
+    return out
+
+
+def score_rank(x, ent, bias, obj, target, label, ent_row0=0, counts=None):
+    """counts [B, 3] int64 += (gt, ties_lower, ties) over this shard's entities."""
+    B, n, O = _score_args(x, ent, bias)
+    if obj.numel() != B or target.numel() != B or label.dim() != 2 or label.size(0) != B or label.size(1) != n:
+        raise NativeError('score_rank: obj/target/label do not match batch %d x shard %d' % (B, n))
+    if counts is None:
+        counts = torch.zeros((B, 3), dtype=torch.int64, device=x.device)
+    _check(lib().mgcn_score_rank(B, n, int(ent_row0), O, _dev(x, torch.float32, 'x'), _ld(x),
+                                 _dev(ent, torch.float32, 'ent'), _ld(ent), _dev(bias, torch.float32, 'bias'),
+                                 _dev(obj, torch.int64, 'obj'), _dev(target, torch.float32, 'target'),
+                                 _dev(label, torch.float32, 'label'), _ld(label), _dev(counts, torch.int64, 'counts'),
+                                 _stream(x)), 'mgcn_score_rank')
+    return counts

@@ -1,0 +1,426 @@
+// Relation- and edge-typed neighbour aggregation over CSR-by-destination slots (gfx950).
+//
+// Forward: one LANE GROUP per (half, destination) walks that destination's slots in slot order
+// and keeps the partial sum in registers; every lane owns VEC consecutive columns of the row, so
+// a slot costs one broadcast 16-B record load plus three row loads (x gather, relation row,
+// per-edge row — a pure stream when the table is laid out in slot order). One plain store per
+// destination row: no atomics, sums reproducible and in the same order as a CPU scatter-add.
+// Row width D = 100 f32 = 25 dwordx4: two 32-lane groups per 64-lane wave (SURVEY §7 "Row width").
+//
+// HBM-bound integer/float streaming work: nothing here is reshaped into a GEMM.
+#include <hip/hip_runtime.h>
+
+#include "mgcn_common.h"
+
+namespace {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  using type = float4;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+  static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+  static __device__ __forceinline__ float4 mul(float4 a, float4 b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+  }
+  static __device__ __forceinline__ float4 muls(float4 a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+  }
+  static __device__ __forceinline__ float4 add(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+};
+template <>
+struct Vec<1> {
+  using type = float;
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ float load(const float *p) { return *p; }
+  static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+  static __device__ __forceinline__ float mul(float a, float b) { return a * b; }
+  static __device__ __forceinline__ float muls(float a, float s) { return a * s; }
+  static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+};
+
+struct AggArgs {
+  const int32_t *rowptr;  // [2][N+1]
+  const int4 *rec;        // [2E] {src, type, norm bits, eid}
+  const float *x;
+  const float *rel;
+  const float *ee;  // may be null
+  const float *loop_edge;
+  float *a;
+  int64_t ldx, lda;
+  int32_t n, e, d, rel_rows, ee_slot_order, modes;
+};
+
+// GS lanes per group (power of two <= 64), CPL column chunks per lane.
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lane_in_group = threadIdx.x & (gs - 1);
+  const int64_t item = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (item >= int64_t(p.modes) * p.n) return;
+  const int mode = int(item / p.n);
+  const int node = int(item - int64_t(mode) * p.n);
+  const int nchunk = p.d / VEC;
+
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+
+  if (mode == 2) {  // self loop: (x * rel[last]) * loop_edge, model.py:91-94,101
+    const float *xr = p.x + int64_t(node) * p.ldx;
+    const float *rr = p.rel + int64_t(p.rel_rows - 1) * p.d;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ch = lane_in_group + c * gs;
+      if (ch < nchunk)
+        V::store(p.a + int64_t(node) * p.lda + 2 * p.d + ch * VEC,
+                 V::mul(V::mul(V::load(xr + ch * VEC), V::load(rr + ch * VEC)), V::load(p.loop_edge + ch * VEC)));
+    }
+    return;
+  }
+
+  const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);
+  const int beg = rp[node], end = rp[node + 1];
+  const int64_t base = int64_t(mode) * p.e;
+  for (int s = beg; s < end; ++s) {
+    const int4 r = p.rec[base + s];
+    const float w = __int_as_float(r.z);
+    const float *xr = p.x + int64_t(r.x) * p.ldx;
+    const float *rr = p.rel + int64_t(r.y) * p.d;
+    const float *er = p.ee ? p.ee + (p.ee_slot_order ? (base + s) : int64_t(r.w)) * p.d : nullptr;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ch = lane_in_group + c * gs;
+      if (ch < nchunk) {
+        T m = V::mul(V::load(xr + ch * VEC), V::load(rr + ch * VEC));
+        if (er) m = V::mul(m, V::load(er + ch * VEC));
+        acc[c] = V::add(acc[c], V::muls(m, w));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane_in_group + c * gs;
+    if (ch < nchunk) V::store(p.a + int64_t(node) * p.lda + mode * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward
+// ---------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const int4 *rec;
+  const int32_t *slot_dst;
+  const int32_t *srcptr;     // [2][N+1]
+  const int32_t *srcslots;   // [2E]
+  const int32_t *typeptr;    // [T+1]
+  const int32_t *typeslots;  // [2E]
+  const float *x, *rel, *ee, *g;
+  float *gx, *gee, *grel, *ws;
+  int64_t ldx, ldg;
+  int32_t n, e, d, rel_rows, nchunks_type;
+};
+
+constexpr int kTypeChunk = 64;  // slots per partial sum of the by-type reduction
+
+// gee[slot] = (g[dst, half] * norm) * x[src] * rel[type]; one group per slot, fully streamed store.
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_gee_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t slot = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (slot >= 2 * int64_t(p.e)) return;
+  const int nchunk = p.d / VEC;
+  const int4 r = p.rec[slot];
+  const float w = __int_as_float(r.z);
+  const int half = slot >= p.e;
+  const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+  const float *xr = p.x + int64_t(r.x) * p.ldx;
+  const float *rr = p.rel + int64_t(r.y) * p.d;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) {
+      T gm = V::muls(V::load(gr + ch * VEC), w);
+      V::store(p.gee + slot * p.d + ch * VEC, V::mul(V::mul(gm, V::load(xr + ch * VEC)), V::load(rr + ch * VEC)));
+    }
+  }
+}
+
+// gx[node] = sum over both halves' by-source lists of (g[dst, half] * norm) * rel[type] * ee[slot].
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_gx_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t node = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (node >= p.n) return;
+  const int nchunk = p.d / VEC;
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  for (int half = 0; half < 2; ++half) {
+    const int32_t *sp = p.srcptr + int64_t(half) * (p.n + 1);
+    const int beg = sp[node], end = sp[node + 1];
+    for (int i = beg; i < end; ++i) {
+      const int slot = p.srcslots[int64_t(half) * p.e + i];
+      const int4 r = p.rec[slot];
+      const float w = __int_as_float(r.z);
+      const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+      const float *rr = p.rel + int64_t(r.y) * p.d;
+      const float *er = p.ee ? p.ee + int64_t(slot) * p.d : nullptr;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) {
+          T m = V::mul(V::muls(V::load(gr + ch * VEC), w), V::load(rr + ch * VEC));
+          if (er) m = V::mul(m, V::load(er + ch * VEC));
+          acc[c] = V::add(acc[c], m);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) V::store(p.gx + node * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// By-type reduction, stage 1: entries [c*CH, (c+1)*CH) of typeslots; every maximal run of one type
+// inside the chunk is summed in entry order and stored to a partial row: row `c` if the run starts at
+// the chunk boundary (and not at a type boundary), row nchunks + t if it starts at typeptr[t].
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_grel_partial_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t chunk = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (chunk >= p.nchunks_type) return;
+  const int nchunk = p.d / VEC;
+  const int64_t e2 = 2 * int64_t(p.e);
+  const int64_t lo = chunk * kTypeChunk;
+  const int64_t hi = (lo + kTypeChunk < e2) ? lo + kTypeChunk : e2;
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  int cur_type = p.rec[p.typeslots[lo]].y;
+  int64_t out_row = (p.typeptr[cur_type] == lo) ? int64_t(p.nchunks_type) + cur_type : chunk;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int slot = p.typeslots[i];
+    const int4 r = p.rec[slot];
+    if (r.y != cur_type) {  // uniform across the group
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) V::store(p.ws + out_row * p.d + ch * VEC, acc[c]);
+        acc[c] = V::zero();
+      }
+      cur_type = r.y;
+      out_row = int64_t(p.nchunks_type) + cur_type;  // a new type inside a chunk starts at typeptr[type]
+    }
+    const float w = __int_as_float(r.z);
+    const int half = slot >= p.e;
+    const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+    const float *xr = p.x + int64_t(r.x) * p.ldx;
+    const float *er = p.ee ? p.ee + int64_t(slot) * p.d : nullptr;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int ch = lig + c * gs;
+      if (ch < nchunk) {
+        T m = V::mul(V::muls(V::load(gr + ch * VEC), w), V::load(xr + ch * VEC));
+        if (er) m = V::mul(m, V::load(er + ch * VEC));
+        acc[c] = V::add(acc[c], m);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) V::store(p.ws + out_row * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// Stage 2: grel[t] = partial[nchunks + t] + partial[c] for every chunk boundary strictly inside t's range.
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_grel_final_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t t = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (t >= p.rel_rows) return;
+  const int nchunk = p.d / VEC;
+  const int64_t lo = p.typeptr[t], hi = p.typeptr[t + 1];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch >= nchunk) continue;
+    T acc = V::zero();
+    if (hi > lo) {
+      acc = V::load(p.ws + (int64_t(p.nchunks_type) + t) * p.d + ch * VEC);
+      for (int64_t cb = lo / kTypeChunk + 1; cb * kTypeChunk < hi; ++cb)
+        acc = V::add(acc, V::load(p.ws + cb * p.d + ch * VEC));
+    }
+    V::store(p.grel + t * p.d + ch * VEC, acc);
+  }
+}
+
+struct Geometry {
+  int vec, cpl, gs_log2;
+};
+
+// lanes per group: the smallest power of two covering the row's chunks, capped at one wave.
+bool pick_geometry(int d, bool all_aligned, Geometry *g) {
+  g->vec = (d % 4 == 0 && all_aligned) ? 4 : 1;
+  const int nchunk = d / g->vec;
+  int gl = 2;  // at least 4 lanes
+  while ((1 << gl) < nchunk && gl < 6) ++gl;
+  g->gs_log2 = gl;
+  const int cpl = (nchunk + (1 << gl) - 1) >> gl;
+  g->cpl = cpl <= 1 ? 1 : cpl <= 2 ? 2 : cpl <= 4 ? 4 : cpl <= 8 ? 8 : 0;
+  return g->cpl != 0;
+}
+
+#define MGCN_LAUNCH_GEOM(KERNEL, ARGS, ITEMS, GEOM, STREAM)                                               \
+  do {                                                                                                    \
+    const int64_t threads_ = int64_t(ITEMS) << (GEOM).gs_log2;                                            \
+    const unsigned grid_ = unsigned((threads_ + 255) / 256);                                              \
+    if (grid_ > 0) {                                                                                      \
+      hipStream_t s_ = static_cast<hipStream_t>(STREAM);                                                  \
+      if ((GEOM).vec == 4) {                                                                              \
+        switch ((GEOM).cpl) {                                                                             \
+          case 1: hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          case 2: hipLaunchKernelGGL((KERNEL<4, 2>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          case 4: hipLaunchKernelGGL((KERNEL<4, 4>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          default: hipLaunchKernelGGL((KERNEL<4, 8>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+        }                                                                                                 \
+      } else {                                                                                            \
+        switch ((GEOM).cpl) {                                                                             \
+          case 1: hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          case 2: hipLaunchKernelGGL((KERNEL<1, 2>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          case 4: hipLaunchKernelGGL((KERNEL<1, 4>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+          default: hipLaunchKernelGGL((KERNEL<1, 8>), dim3(grid_), dim3(256), 0, s_, ARGS, (GEOM).gs_log2); break; \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+
+}  // namespace
+
+extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
+                                  const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
+                                  int64_t ldx, const float *rel_dev, const float *ee_dev, int32_t ee_in_slot_order,
+                                  const float *loop_edge_dev, float *a_dev, int64_t lda, void *stream) {
+  MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_fwd: bad sizes");
+  MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
+               "aggregate_fwd: sizes exceed int32");
+  MGCN_REQUIRE(rowptr_dev && x_dev && rel_dev && a_dev, "aggregate_fwd: null pointer");
+  MGCN_REQUIRE(num_edges_half == 0 || rec_dev, "aggregate_fwd: null rec");
+  const int modes = loop_edge_dev ? 3 : 2;
+  MGCN_REQUIRE(ldx >= dim && lda >= int64_t(modes) * dim, "aggregate_fwd: ldx/lda too small");
+  if (num_nodes == 0) return MGCN_OK;
+  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(a_dev) &&
+                       (!ee_dev || mgcn::aligned16(ee_dev)) && (!loop_edge_dev || mgcn::aligned16(loop_edge_dev)) &&
+                       ldx % 4 == 0 && lda % 4 == 0;
+  Geometry g;
+  if (!pick_geometry(dim, aligned, &g)) return mgcn::fail(MGCN_EUNSUPPORTED, "aggregate_fwd: dim %d too wide", dim);
+  AggArgs p;
+  p.rowptr = rowptr_dev;
+  p.rec = reinterpret_cast<const int4 *>(rec_dev);
+  p.x = x_dev;
+  p.rel = rel_dev;
+  p.ee = ee_dev;
+  p.loop_edge = loop_edge_dev;
+  p.a = a_dev;
+  p.ldx = ldx;
+  p.lda = lda;
+  p.n = int32_t(num_nodes);
+  p.e = int32_t(num_edges_half);
+  p.d = dim;
+  p.rel_rows = num_rel_rows;
+  p.ee_slot_order = ee_in_slot_order;
+  p.modes = modes;
+  MGCN_LAUNCH_GEOM(agg_fwd_kernel, p, int64_t(modes) * num_nodes, g, stream);
+  MGCN_CHECK_LAUNCH("agg_fwd_kernel");
+  return MGCN_OK;
+}
+
+extern "C" size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows) {
+  const int64_t nchunks = (2 * num_edges_half + kTypeChunk - 1) / kTypeChunk;
+  return size_t(nchunks + num_rel_rows) * size_t(dim) * sizeof(float);
+}
+
+extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
+                                  const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev,
+                                  const int32_t *srcptr_dev, const int32_t *srcslots_dev,
+                                  const int32_t *typeptr_dev, const int32_t *typeslots_dev, const float *x_dev,
+                                  int64_t ldx, const float *rel_dev, const float *ee_dev, const float *g_dev,
+                                  int64_t ldg, float *gx_dev, float *gee_dev, float *grel_dev,
+                                  float *workspace_dev, size_t workspace_bytes, void *stream) {
+  MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_bwd: bad sizes");
+  MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
+               "aggregate_bwd: sizes exceed int32");
+  MGCN_REQUIRE(x_dev && rel_dev && g_dev, "aggregate_bwd: null pointer");
+  MGCN_REQUIRE(num_edges_half == 0 || (rec_dev && slot_dst_dev), "aggregate_bwd: null slot arrays");
+  MGCN_REQUIRE(ldx >= dim && ldg >= 2 * int64_t(dim), "aggregate_bwd: ldx/ldg too small");
+  MGCN_REQUIRE(!gx_dev || (srcptr_dev && (num_edges_half == 0 || srcslots_dev)), "aggregate_bwd: gx needs srcptr/srcslots");
+  MGCN_REQUIRE(!grel_dev || (typeptr_dev && (num_edges_half == 0 || typeslots_dev)), "aggregate_bwd: grel needs typeptr/typeslots");
+  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(g_dev) &&
+                       (!ee_dev || mgcn::aligned16(ee_dev)) && (!gx_dev || mgcn::aligned16(gx_dev)) &&
+                       (!gee_dev || mgcn::aligned16(gee_dev)) && (!grel_dev || mgcn::aligned16(grel_dev)) &&
+                       (!workspace_dev || mgcn::aligned16(workspace_dev)) && ldx % 4 == 0 && ldg % 4 == 0;
+  Geometry g;
+  if (!pick_geometry(dim, aligned, &g)) return mgcn::fail(MGCN_EUNSUPPORTED, "aggregate_bwd: dim %d too wide", dim);
+  BwdArgs p;
+  p.rec = reinterpret_cast<const int4 *>(rec_dev);
+  p.slot_dst = slot_dst_dev;
+  p.srcptr = srcptr_dev;
+  p.srcslots = srcslots_dev;
+  p.typeptr = typeptr_dev;
+  p.typeslots = typeslots_dev;
+  p.x = x_dev;
+  p.rel = rel_dev;
+  p.ee = ee_dev;
+  p.g = g_dev;
+  p.gx = gx_dev;
+  p.gee = gee_dev;
+  p.grel = grel_dev;
+  p.ws = workspace_dev;
+  p.ldx = ldx;
+  p.ldg = ldg;
+  p.n = int32_t(num_nodes);
+  p.e = int32_t(num_edges_half);
+  p.d = dim;
+  p.rel_rows = num_rel_rows;
+  p.nchunks_type = int32_t((2 * num_edges_half + kTypeChunk - 1) / kTypeChunk);
+  if (gee_dev && num_edges_half > 0) {
+    MGCN_LAUNCH_GEOM(agg_bwd_gee_kernel, p, 2 * num_edges_half, g, stream);
+    MGCN_CHECK_LAUNCH("agg_bwd_gee_kernel");
+  }
+  if (gx_dev && num_nodes > 0) {
+    MGCN_LAUNCH_GEOM(agg_bwd_gx_kernel, p, num_nodes, g, stream);
+    MGCN_CHECK_LAUNCH("agg_bwd_gx_kernel");
+  }
+  if (grel_dev) {
+    MGCN_REQUIRE(workspace_dev && workspace_bytes >= mgcn_aggregate_bwd_workspace(num_edges_half, dim, num_rel_rows),
+                 "aggregate_bwd: workspace too small");
+    if (p.nchunks_type > 0) {
+      MGCN_LAUNCH_GEOM(agg_bwd_grel_partial_kernel, p, p.nchunks_type, g, stream);
+      MGCN_CHECK_LAUNCH("agg_bwd_grel_partial_kernel");
+    }
+    MGCN_LAUNCH_GEOM(agg_bwd_grel_final_kernel, p, num_rel_rows, g, stream);
+    MGCN_CHECK_LAUNCH("agg_bwd_grel_final_kernel");
+  }
+  return MGCN_OK;
+}

@@ -1,0 +1,96 @@
+"""Graph containers: the attribute bag the reference's loops pass around, and the device-side CSR.
+
+`Graph` stands where torch_geometric.data.Data stands in the reference (data_loader.py:151-155,
+model.py:25-26, main.py:206): same attribute names, `.to(device)` moves everything IN PLACE
+(main.py:206 discards the return value). `GraphCSR` is the build's own layout of the same edges:
+per-half CSR by destination with the degree norms folded into 16-byte slot records.
+"""
+import torch
+
+from . import _native
+
+
+class GraphCSR(object):
+    """Device-resident slot arrays produced by mgcn_csr_build_host (include/mgcn_hip.h (1))."""
+
+    _FIELDS = ('rowptr', 'rec', 'perm', 'slot_dst', 'srcptr', 'srcslots', 'typeptr', 'typeslots')
+
+    def __init__(self, num_nodes, num_rel_rows, edge_index, edge_type, device, with_backward=True):
+        host = _native.csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward)
+        self.num_nodes = int(num_nodes)
+        self.num_edges_half = int(edge_index.size(1)) // 2
+        self.num_rel_rows = int(num_rel_rows)
+        self.has_backward = with_backward
+        for k in self._FIELDS:
+            setattr(self, k, host[k].to(device) if k in host else None)
+        self._inv_perm = None
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def to(self, device):
+        for k in self._FIELDS:
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.to(device))
+        self._inv_perm = None
+        return self
+
+    @property
+    def inv_perm(self):
+        """reference edge id -> slot."""
+        if self._inv_perm is None:
+            inv = torch.empty_like(self.perm)
+            inv[self.perm] = torch.arange(self.perm.numel(), device=self.perm.device)
+            self._inv_perm = inv
+        return self._inv_perm
+
+    def norms(self):
+        """Per-slot degree norm (f32 view of the record's third word)."""
+        return self.rec[:, 2].contiguous().view(torch.float32)
+
+
+class Graph(object):
+    def __init__(self, edge_index=None, edge_attr=None, **kwargs):
+        self.edge_index = edge_index
+        self.edge_attr = edge_attr
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+        self._csr = {}
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                setattr(self, k, v.to(device))
+        for c in self._csr.values():
+            c.to(device)
+        return self
+
+    def csr(self, num_rel_rows, with_backward=True):
+        """CSR of this graph's edges for a relation table with `num_rel_rows` rows (cached)."""
+        dev = self.edge_index.device
+        key = (int(num_rel_rows), self.edge_index.data_ptr(), self.edge_attr.data_ptr(), str(dev))
+        hit = self._csr.get(key)
+        if hit is None or (with_backward and not hit.has_backward):
+            self._csr.clear()
+            n = self.num_nodes if getattr(self, 'num_nodes', None) is not None else int(self.edge_index.max()) + 1
+            hit = GraphCSR(n, num_rel_rows, self.edge_index, self.edge_attr[0], dev, with_backward)
+            self._csr[key] = hit
+        return hit
+
+
+_tensor_csr_cache = {}
+
+
+def csr_for_tensors(num_nodes, num_rel_rows, edge_index, edge_type):
+    """Operator-level seam (MGCNConv.forward called with bare tensors, model.py:82): cache by identity."""
+    key = (int(num_nodes), int(num_rel_rows), edge_index.data_ptr(), edge_type.data_ptr(), tuple(edge_index.shape),
+           edge_index._version, edge_type._version, str(edge_index.device))
+    hit = _tensor_csr_cache.get(key)
+    if hit is None:
+        if len(_tensor_csr_cache) > 8:
+            _tensor_csr_cache.clear()
+        hit = GraphCSR(num_nodes, num_rel_rows, edge_index, edge_type, edge_index.device)
+        _tensor_csr_cache[key] = hit
+    return hit

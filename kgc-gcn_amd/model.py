@@ -1,0 +1,287 @@
+"""M-GCN model with the reference's model.py surface (MGCN, MGCNConv, ConvE; model.py:9-181), so
+main.py's train / predict loops are drop-in callers, and state-dict keys match so reference
+checkpoints load.
+
+What runs where
+  * neighbour aggregation (model.py:99-101,111-118 + identity gathers 29-30, norms 72-80): HIP, forward
+    and backward (kgc-gcn_amd/csrc/aggregate.hip) over the slot-ordered CSR of graph.GraphCSR;
+  * eval-mode layer epilogue (model.py:103-107): the f32-MFMA dense step fused with /3, bias, BN, tanh
+    (csrc/dense.hip). In training mode (batch statistics, dropout) the dense step + BN go through
+    torch's own GPU ops so autograd covers them;
+  * full-graph scoring (model.py:177-179) and the filtered rank counts (main.py:122-126): HIP;
+  * the ConvE conv trunk (model.py:161-175): stock torch modules (MIOpen / rocBLAS), out of scope.
+There is no CPU path: tensors that are not on a GPU make the native layer raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _native
+from .graph import csr_for_tensors
+from .utils import get_param
+
+
+class _AggregateFn(torch.autograd.Function):
+    """A[:, :D] / A[:, D:2D] = in-/out-half aggregates; gradients by the HIP backward kernels."""
+
+    @staticmethod
+    def forward(ctx, x, rel, ee_slot, csr):
+        out = torch.empty((x.size(0), 2 * x.size(1)), dtype=torch.float32, device=x.device)
+        _native.aggregate_fwd(csr, x, rel, ee_slot, True, None, out)
+        ctx.save_for_backward(x, rel, ee_slot)
+        ctx.csr = csr
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, rel, ee = ctx.saved_tensors
+        gx, gee, grel = _native.aggregate_bwd(ctx.csr, x, rel, ee, g.contiguous(), want_gx=ctx.needs_input_grad[0],
+                                              want_gee=ctx.needs_input_grad[2], want_grel=ctx.needs_input_grad[1])
+        return gx, grel, gee, None
+
+
+class _ScoreFn(torch.autograd.Function):
+    """sigmoid(x @ ent^T + bias): forward on the HIP tile kernel, backward as three plain GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, ent, bias):
+        s = _native.score_fwd(x, ent, bias)
+        ctx.save_for_backward(x, ent, s)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        x, ent, s = ctx.saved_tensors
+        gz = gs * s * (1.0 - s)
+        return (gz @ ent if ctx.needs_input_grad[0] else None,
+                gz.t() @ x if ctx.needs_input_grad[1] else None,
+                gz.sum(0) if ctx.needs_input_grad[2] else None)
+
+
+class MGCNConv(nn.Module):
+    """One relational layer (model.py:47-127). Parameter names are the reference's."""
+
+    def __init__(self, in_channels, out_channels, num_relations, bias=False, dropout=0.1, **kwargs):
+        super(MGCNConv, self).__init__()
+        self.in_channels, self.out_channels, self.num_relations = in_channels, out_channels, num_relations
+        self.ent_bn = nn.BatchNorm1d(out_channels)
+        self.drop = nn.Dropout(dropout)
+        self.act = torch.tanh
+        self.loop_weight = get_param((in_channels, out_channels))
+        self.in_weight = get_param((in_channels, out_channels))
+        self.out_weight = get_param((in_channels, out_channels))
+        self.rels_weight = get_param((in_channels, out_channels))
+        self.loop_rel = get_param((1, in_channels))
+        self.loop_edge = get_param((1, in_channels))
+        self.register_parameter('bias', nn.Parameter(torch.zeros(out_channels)) if bias is True else None)
+
+    def compute_norm(self, edge_index, num_ent):
+        """deg^-1/2[row] * deg^-1/2[col], degrees counted by source (model.py:72-80). The layer itself reads
+        the same values out of the slot records; this method exists for callers of the reference API."""
+        row, col = edge_index
+        deg = torch.bincount(row, minlength=num_ent).to(torch.float32)
+        inv = deg.pow(-0.5)
+        inv[inv == float('inf')] = 0
+        return inv[row] * inv[col]
+
+    def forward(self, x, edge_index, edge_type, edge_norm, edge_embs, rels_embs, size=None, csr=None,
+                ee_in_slot_order=False):
+        """Returns (all_ent [N, O], all_rel [2R, O]). `edge_norm` is ignored, as in the reference (Q1).
+        `csr` / `ee_in_slot_order` are the fast-path hand-over from MGCN.forward: the graph's cached CSR and a
+        per-edge table already laid out in slot order."""
+        num_ent = x.size(0)
+        rels = torch.cat([rels_embs, self.loop_rel], dim=0)
+        if csr is None:
+            csr = csr_for_tensors(num_ent, rels.size(0), edge_index, edge_type)
+        tracked = torch.is_grad_enabled() and (
+            x.requires_grad or edge_embs.requires_grad or rels_embs.requires_grad
+            or any(p.requires_grad for p in self.parameters()))
+        x = x.contiguous()
+        if not self.training and not tracked:
+            agg = torch.empty((num_ent, 3 * self.in_channels), dtype=torch.float32, device=x.device)
+            _native.aggregate_fwd(csr, x, rels, edge_embs.contiguous(), ee_in_slot_order,
+                                  self.loop_edge.reshape(-1), agg)
+            all_ent = torch.empty((num_ent, self.out_channels), dtype=torch.float32, device=x.device)
+            bn = self.ent_bn
+            _native.dense_bn_tanh_fwd(agg, self.in_weight, self.out_weight, self.loop_weight, self.bias,
+                                      bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
+            all_rel = _native.matmul(rels, self.rels_weight)[:-1]
+            return all_ent, all_rel
+
+        ee = edge_embs if ee_in_slot_order else edge_embs.index_select(0, csr.perm)
+        agg = _AggregateFn.apply(x, rels, ee.contiguous(), csr)
+        d = self.in_channels
+        in_res = agg[:, :d] @ self.in_weight
+        out_res = agg[:, d:] @ self.out_weight
+        loop_res = ((x * rels[-1]) * self.loop_edge) @ self.loop_weight
+        out = (self.drop(in_res) + self.drop(out_res) + loop_res) / 3
+        if self.bias is not None:
+            out = out + self.bias
+        all_ent = self.act(self.ent_bn(out))
+        all_rel = torch.matmul(rels, self.rels_weight)[:-1]
+        return all_ent, all_rel
+
+    def __repr__(self):
+        return '{}({}, {}, num_relations={})'.format(self.__class__.__name__, self.in_channels, self.out_channels,
+                                                     self.num_relations)
+
+
+class ConvE(nn.Module):
+    """Decoder (model.py:130-181): torch conv trunk, HIP scoring against every entity."""
+
+    def __init__(self, params, num_entities):
+        super(ConvE, self).__init__()
+        self.params = params
+        self.bn0 = nn.BatchNorm2d(1)
+        self.bn1 = nn.BatchNorm2d(params.num_filter)
+        self.bn2 = nn.BatchNorm1d(params.gcn_out_dim)
+        self.hidden_drop = nn.Dropout(params.hidden_drop)
+        self.feature_drop = nn.Dropout(params.feat_drop)
+        self.conv_e = nn.Conv2d(1, params.num_filter, (params.kernel_size, params.kernel_size), stride=1, padding=0,
+                                bias=params.bias)
+        h = 2 * int(params.k_w) - params.kernel_size + 1
+        w = params.k_h - params.kernel_size + 1
+        self.flat_sz = h * w * params.num_filter
+        self.fc = nn.Linear(self.flat_sz, params.gcn_out_dim)
+        self.register_parameter('bias', nn.Parameter(torch.zeros(num_entities)))
+
+    def trunk(self, src_emb, rel_emb):
+        o = self.params.gcn_out_dim
+        stack = torch.cat([src_emb.view(-1, 1, o), rel_emb.view(-1, 1, o)], dim=1)
+        stack = stack.transpose(2, 1).reshape(-1, 1, 2 * self.params.k_w, self.params.k_h)
+        x = self.feature_drop(F.relu(self.bn1(self.conv_e(self.bn0(stack)))))
+        x = self.hidden_drop(self.fc(x.view(-1, self.flat_sz)))
+        return F.relu(self.bn2(x)).contiguous()
+
+    def forward(self, src_emb, rel_emb, all_ent):
+        x = self.trunk(src_emb, rel_emb)
+        return _ScoreFn.apply(x, all_ent.contiguous(), self.bias)
+
+
+class MGCN(nn.Module):
+    """model.py:9-44. forward(src [B], rel [B], data) -> score [B, N] in (0, 1)."""
+
+    def __init__(self, num_entities, num_relations, num_edges, params):
+        super(MGCN, self).__init__()
+        self.params = params
+        self.entity_embedding = get_param((num_entities, params.gcn_in_dim))
+        self.relation_embedding = get_param((2 * num_relations, params.gcn_in_dim))
+        self.edge_embeddings = get_param((2 * num_edges, params.gcn_in_dim))
+        self.conv1 = MGCNConv(params.gcn_in_dim, params.gcn_out_dim, num_relations * 2)
+        self.conv2 = ConvE(params, num_entities)
+        self.loss_fn = nn.BCELoss()
+        # stacking beyond the reference's single layer (BASELINE.json "2-layer"): each extra layer
+        # is out->out with its own per-edge table; created AFTER everything above so that seeding of the
+        # reference's parameters is unchanged.
+        extra = int(getattr(params, 'gcn_layers', 1)) - 1
+        self.conv1_extra = nn.ModuleList(
+            [MGCNConv(params.gcn_out_dim, params.gcn_out_dim, num_relations * 2) for _ in range(extra)])
+        self.edge_embeddings_extra = nn.ParameterList(
+            [get_param((2 * num_edges, params.gcn_out_dim)) for _ in range(extra)])
+        self._slot_csr = None      # per-edge tables are stored in this CSR's slot order (None = reference order)
+        self._enc_cache = None
+        self._register_state_dict_hook(MGCN._to_reference_order)
+        self.register_load_state_dict_post_hook(MGCN._loaded_reference_order)
+
+    # -- per-edge table layout ------------------------------------------------------------------
+    def _edge_tables(self):
+        return [('edge_embeddings', self.edge_embeddings)] + \
+               [('edge_embeddings_extra.%d' % i, p) for i, p in enumerate(self.edge_embeddings_extra)]
+
+    @staticmethod
+    def _to_reference_order(module, state_dict, prefix, local_metadata):
+        if module._slot_csr is not None:
+            inv = module._slot_csr.inv_perm
+            for name, _ in module._edge_tables():
+                t = state_dict[prefix + name]
+                state_dict[prefix + name] = t.index_select(0, inv.to(t.device))
+        return state_dict
+
+    @staticmethod
+    def _loaded_reference_order(module, incompatible_keys):
+        module._slot_csr = None
+        module._enc_cache = None
+
+    def _use_slot_order(self, csr):
+        """Lay the per-edge tables out in `csr`'s slot order, in place, once per graph: the aggregation kernel
+        then STREAMS them (58 % of a WN18RR layer's bytes) instead of gathering rows by edge id. Gradients and
+        optimizer state follow the same order; state_dict() converts back (reference order on disk)."""
+        if self._slot_csr is csr:
+            return
+        with torch.no_grad():
+            for _, p in self._edge_tables():
+                t = p.data if self._slot_csr is None else p.data.index_select(0, self._slot_csr.inv_perm)
+                p.data.copy_(t.index_select(0, csr.perm))
+        self._slot_csr = csr
+
+    # -- encoder ---------------------------------------------------------------------------------
+    def _graph_facts(self, data):
+        facts = getattr(data, '_mgcn_facts', None)
+        key = (data.entity.data_ptr(), data.edge_attr.data_ptr())
+        if facts is None or facts[0] != key:
+            n, e2 = self.entity_embedding.size(0), self.edge_embeddings.size(0)
+            ent_id = data.entity.numel() == n and bool((data.entity == torch.arange(n, device=data.entity.device)).all())
+            ids = data.edge_attr[1]
+            edge_id = ids.numel() == e2 and bool((ids == torch.arange(e2, device=ids.device)).all())
+            facts = (key, ent_id, edge_id)
+            data._mgcn_facts = facts
+        return facts[1], facts[2]
+
+    def encode(self, data):
+        """model.py:25-34: (all_ent [N, O], all_rel [2R, O]) for the whole graph."""
+        edge_type, edge_ids = data.edge_attr
+        ent_identity, edge_identity = self._graph_facts(data)
+        num_rel_rows = self.relation_embedding.size(0) + 1
+        csr = data.csr(num_rel_rows) if hasattr(data, 'csr') else csr_for_tensors(
+            self.entity_embedding.size(0), num_rel_rows, data.edge_index, edge_type)
+
+        frozen = not self.training and not torch.is_grad_enabled()
+        if frozen and getattr(self.params, 'cache_encoder', True):
+            stamp = (id(csr),) + tuple(t._version for t in self._encoder_tensors()) + tuple(
+                t.data_ptr() for t in self._encoder_tensors())
+            if self._enc_cache is not None and self._enc_cache[0] == stamp:
+                return self._enc_cache[1], self._enc_cache[2]
+
+        x = self.entity_embedding if ent_identity else torch.index_select(self.entity_embedding, 0, data.entity)
+        rel = self.relation_embedding
+        layers = [self.conv1] + list(self.conv1_extra)
+        tables = [self.edge_embeddings] + list(self.edge_embeddings_extra)
+        if edge_identity:
+            self._use_slot_order(csr)
+        for layer, table in zip(layers, tables):
+            ee = table if edge_identity else torch.index_select(table, 0, edge_ids)
+            x, rel = layer(x, data.edge_index, edge_type, getattr(data, 'edge_norm', None), ee, rel, csr=csr,
+                           ee_in_slot_order=edge_identity)
+            x = F.dropout(x, p=self.params.gcn_drop, training=self.training)
+        if frozen and getattr(self.params, 'cache_encoder', True):
+            stamp = (id(csr),) + tuple(t._version for t in self._encoder_tensors()) + tuple(
+                t.data_ptr() for t in self._encoder_tensors())
+            self._enc_cache = (stamp, x, rel)
+        return x, rel
+
+    def _encoder_tensors(self):
+        ts = [self.entity_embedding, self.relation_embedding, self.edge_embeddings] + list(self.edge_embeddings_extra)
+        for layer in [self.conv1] + list(self.conv1_extra):
+            ts += list(layer.parameters()) + list(layer.buffers())
+        return ts
+
+    # -- reference surface -----------------------------------------------------------------------
+    def forward(self, src, rel, data):
+        all_ent, all_rel = self.encode(data)
+        src_emb, rel_emb = torch.index_select(all_ent, 0, src), torch.index_select(all_rel, 0, rel)
+        return self.conv2(src_emb, rel_emb, all_ent)
+
+    def loss(self, pred, label):
+        return self.loss_fn(pred, label)
+
+    # -- fused evaluation path (main.py:121-126 without materialising [B, N] scores) -------------
+    @torch.no_grad()
+    def rank_counts(self, src, rel, obj, label, data):
+        """Per query: gt / ties_lower / ties (int64 [B, 3]) and the target score [B]. Filtered rank under the
+        stable tie rule = 1 + gt + ties_lower; on rows with ties == 0 it equals the reference's rank exactly."""
+        all_ent, all_rel = self.encode(data)
+        x = self.conv2.trunk(torch.index_select(all_ent, 0, src), torch.index_select(all_rel, 0, rel))
+        ent = all_ent.contiguous()
+        target = _native.score_target(x, ent, self.conv2.bias, obj)
+        counts = _native.score_rank(x, ent, self.conv2.bias, obj, target, label.contiguous())
+        return counts, target

@@ -170,6 +170,8 @@ def run_case(root, name, params_over, scale_tables=1.0, full_model=True, seed=20
 
     torch.manual_seed(seed)
     model = ref_model.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    for k, p in model.named_parameters():            # seeded-init parity (construction order + initialisers)
+        out['init_sum_' + k] = p.detach().double().sum()
     randomize_state(model, state_seed)
     if scale_tables != 1.0:                           # bigger margins between scores
         with torch.no_grad():

@@ -1,0 +1,253 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and the golden vectors,
+on a real MI355X. Integer results bit-exact; floats within the tolerance written at each assert
+(north_star: ranks exact on tie-free rows, MRR within 1e-4)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import ALL_CASES, ENCODER_CASES, FULL_CASES, GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _loader(pkg, g, **over):
+    cwd = os.getcwd()
+    os.chdir(GOLDEN)
+    try:
+        params = types.SimpleNamespace(**dict(g.hp, **over))
+        params.device = torch.device(DEV)
+        dl = pkg.DataLoader(os.path.basename(g.data_dir), params)
+    finally:
+        os.chdir(cwd)
+    return dl, params
+
+
+def _model(pkg, g, **over):
+    dl, params = _loader(pkg, g, **over)
+    dl.graph.to(DEV)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    missing = model.load_state_dict(g.state_dict(), strict=False)
+    assert not missing.unexpected_keys
+    return model.to(DEV), dl, params
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+@pytest.mark.parametrize('ee_mode', ['slot', 'edge', 'none'])
+def test_aggregate_bit_exact_vs_oracle(pkg, oracle, case, ee_mode):
+    """Slot order = CPU scatter-add order and the kernel multiplies/adds without contraction, so the three
+    aggregates equal the oracle's build-order restatement bit for bit."""
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    N, R = int(g['dl_num_entity']), int(g['dl_num_relation'])
+    ee = sd['edge_embeddings'] if ee_mode != 'none' else torch.ones_like(sd['edge_embeddings'])
+    _, want = oracle.aggregate_then_weight(sd, 'conv1.', sd['entity_embedding'], ei, ea[0], ee, sd['relation_embedding'])
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV)
+    x = sd['entity_embedding'].to(DEV)
+    rel = torch.cat([sd['relation_embedding'], sd['conv1.loop_rel']]).to(DEV)
+    D = x.size(1)
+    out = torch.full((N, 3 * D), float('nan'), device=DEV)
+    if ee_mode == 'slot':
+        table = ee.to(DEV).index_select(0, csr.perm)
+    elif ee_mode == 'edge':
+        table = ee.to(DEV)
+    else:
+        table = None
+    pkg._native.aggregate_fwd(csr, x, rel, table, ee_mode == 'slot', sd['conv1.loop_edge'].reshape(-1).to(DEV), out)
+    got = out.cpu()
+    for m in range(3):
+        assert torch.equal(got[:, m * D:(m + 1) * D], want[m]), 'mode %d' % m
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_layer_eval_vs_golden(pkg, case):
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index').to(DEV), g.t('dl_edge_attr').to(DEV)
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, sd['relation_embedding'].size(0), bias='conv1.bias' in sd)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    with torch.no_grad():
+        all_ent, all_rel = conv(sd['entity_embedding'].to(DEV), ei, ea[0], None, sd['edge_embeddings'].to(DEV),
+                                sd['relation_embedding'].to(DEV))
+    # W after the sum + MFMA k-order vs the reference's per-edge order: f32 rounding only
+    np.testing.assert_allclose(all_ent.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(all_rel.cpu().numpy(), g['eval_all_rel'], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_forward_scores_and_ranks_vs_golden(pkg, case):
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    model.eval()
+    for split in ('valid_tail', 'valid_head', 'test_tail', 'test_head'):
+        trip = g.t('dl_q_%s_triple' % split).to(DEV)
+        ds = dl._get_dataset(split, params)
+        label = torch.stack([ds[i][1] for i in range(len(ds))]).to(DEV)
+        with torch.no_grad():
+            score = model(trip[:, 0], trip[:, 1], dl.graph)
+            counts, target = model.rank_counts(trip[:, 0], trip[:, 1], trip[:, 2].contiguous(), label, dl.graph)
+        ref_score = g['eval_%s_score' % split]
+        np.testing.assert_allclose(score.cpu().numpy(), ref_score, rtol=0, atol=2e-5)
+        # the fused kernel's target is the very score the forward produced for (b, obj[b])
+        rows = torch.arange(trip.size(0), device=DEV)
+        assert torch.equal(target, score[rows, trip[:, 2]])
+        # counts agree exactly with counting on our own materialised scores (same arithmetic, integer result)
+        masked = torch.where(label >= 1, torch.full_like(score, -1e7), score)
+        masked[rows, trip[:, 2]] = target
+        gt = (masked > target[:, None]).sum(1)
+        eq = masked == target[:, None]
+        eq[rows, trip[:, 2]] = False
+        idx = torch.arange(score.size(1), device=DEV)[None, :]
+        assert torch.equal(counts[:, 0], gt)
+        assert torch.equal(counts[:, 2], eq.sum(1))
+        assert torch.equal(counts[:, 1], (eq & (idx < trip[:, 2:3])).sum(1))
+        # and with the REFERENCE's ranks wherever the reference's own margin exceeds the float tolerance
+        ref = torch.from_numpy(ref_score)
+        ref_t = torch.from_numpy(g['eval_%s_target' % split])
+        gap = (ref - ref_t[:, None]).abs()
+        gap[torch.arange(ref.size(0)), trip[:, 2].cpu()] = 1.0
+        gap[label.cpu() >= 1] = 1.0
+        safe = gap.min(1).values > 1e-4
+        ranks = (1 + counts[:, 0] + counts[:, 1]).cpu()
+        assert torch.equal(ranks[safe], torch.from_numpy(g['eval_%s_ranks' % split])[safe])
+        assert int(safe.sum()) >= int(0.8 * safe.numel())
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+@pytest.mark.parametrize('fused', [True, False])
+def test_evaluate_vs_reference_evaluate(pkg, case, fused):
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    iters = dl.get_data_loaders(g.hp['batch_size'], 0, params)
+    for split in ('valid', 'test'):
+        res = pkg.harness.evaluate(model, iters, dl.graph, params, split, fused=fused)
+        assert abs(float(res['mrr']) - float(g['evaluate_%s_mrr' % split])) <= 1e-4      # north_star tolerance
+        assert abs(float(res['mr']) - float(g['evaluate_%s_mr' % split])) <= 0.05
+        for k in (1, 3, 10):
+            assert abs(float(res['hits@%d' % k]) - float(g['evaluate_%s_hits@%d' % (split, k)])) <= 0.03
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_train_step_gradients_vs_golden(pkg, case):
+    """main.py:59-66 with dropout 0 / lbl_smooth 0: HIP aggregation backward + torch dense backward."""
+    g = golden(case)
+    model, dl, params = _model(pkg, g, gcn_drop=0.0, hidden_drop=0.0, feat_drop=0.0)
+    model.conv1.drop.p = 0.0
+    model.train()
+    trip, lab = g.t('train_triple').to(DEV), g.t('train_label').to(DEV)
+    pred = model(trip[:, 0], trip[:, 1], dl.graph)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g['train_score'], rtol=0, atol=2e-5)
+    loss = model.loss(pred, lab)
+    assert abs(float(loss) - float(g['train_loss'])) < 1e-5
+    loss.backward()
+    sd_after = model.state_dict()
+    inv = model._slot_csr.inv_perm
+    for k, ref in g.grads().items():
+        p = dict(model.named_parameters())[k]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        if k == 'edge_embeddings':
+            got = got.index_select(0, inv)           # gradients live in slot order, like the table
+        scale = float(ref.abs().max()) + 1e-12
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-5 * scale + 1e-9, err_msg=k)
+    for k in g.z.files:
+        if k.startswith('train_after_') and 'num_batches' not in k:
+            np.testing.assert_allclose(sd_after[k[len('train_after_'):]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('case', ENCODER_CASES)
+def test_encoder_gradients_vs_golden(pkg, case):
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index').to(DEV), g.t('dl_edge_attr').to(DEV)
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, sd['relation_embedding'].size(0))
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).train()
+    conv.drop.p = 0.0
+    x = sd['entity_embedding'].to(DEV).requires_grad_(True)
+    ee = sd['edge_embeddings'].to(DEV).requires_grad_(True)
+    rel = sd['relation_embedding'].to(DEV).requires_grad_(True)
+    all_ent, all_rel = conv(x, ei, ea[0], None, ee, rel)
+    np.testing.assert_allclose(all_ent.detach().cpu().numpy(), g['train_all_ent'], rtol=0, atol=5e-5)
+    ((all_ent * g.t('train_G').to(DEV)).sum() + (all_rel * g.t('train_H').to(DEV)).sum()).backward()
+    got = {'entity_embedding': x.grad, 'edge_embeddings': ee.grad, 'relation_embedding': rel.grad}
+    got.update({'conv1.' + k: p.grad for k, p in conv.named_parameters()})
+    for k, ref in g.grads().items():
+        scale = float(ref.abs().max()) + 1e-12
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref.numpy(), rtol=2e-3, atol=5e-5 * scale + 1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_state_dict_stays_in_reference_order(pkg, case):
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    model.eval()
+    trip = g.t('dl_q_test_tail_triple').to(DEV)
+    with torch.no_grad():
+        model(trip[:, 0], trip[:, 1], dl.graph)          # lays edge_embeddings out in slot order
+    assert model._slot_csr is not None
+    sd = model.state_dict()
+    for k, v in g.state_dict().items():
+        assert torch.equal(sd[k].cpu(), v), k
+
+
+def test_sharded_scoring_counts_add_up(pkg):
+    """Entity table cut into 3 uneven shards: per-shard targets/counts (ent_row0) sum to the unsharded ones."""
+    torch.manual_seed(0)
+    B, N, O = 37, 1000, 40
+    x, ent, bias = torch.randn(B, O, device=DEV), torch.randn(N, O, device=DEV) * 0.3, torch.randn(N, device=DEV) * 0.1
+    obj = torch.randint(0, N, (B,), device=DEV)
+    label = (torch.rand(B, N, device=DEV) < 0.01).float()
+    nat = pkg._native
+    target = nat.score_target(x, ent, bias, obj)
+    counts = nat.score_rank(x, ent, bias, obj, target, label)
+    score = nat.score_fwd(x, ent, bias)
+    assert torch.equal(target, score[torch.arange(B, device=DEV), obj])
+    t2 = torch.zeros(B, device=DEV)
+    c2 = torch.zeros((B, 3), dtype=torch.int64, device=DEV)
+    for lo, hi in ((0, 130), (130, 131), (131, N)):
+        nat.score_target(x, ent[lo:hi], bias[lo:hi], obj, ent_row0=lo, out=t2)
+    for lo, hi in ((0, 130), (130, 131), (131, N)):
+        nat.score_rank(x, ent[lo:hi], bias[lo:hi], obj, t2, label[:, lo:hi], ent_row0=lo, counts=c2)
+    assert torch.equal(t2, target)
+    assert torch.equal(c2, counts)
+
+
+@pytest.mark.parametrize('shape', [('wn18rr', 40943, 11, 86835, 0.0), ('fb15k237', 14541, 237, 272115, 1.1)])
+def test_full_size_layer_vs_oracle(pkg, oracle, shape):
+    """BASELINE.json configs 2-3 at full size (synthetic graphs of the public shapes)."""
+    name, N, R, E, zipf = shape
+    tri = oracle.synthetic_triples(N, R, E, seed=0, zipf=zipf)
+    ei, ea = oracle.build_edge_list(tri, R)
+    ei, ea = torch.from_numpy(ei), torch.from_numpy(ea)
+    gen = torch.Generator().manual_seed(0)
+    D, O = 100, 200
+    sd = oracle.init_layer_state('conv1.', D, O, gen)
+    bound = lambda a, b: float(np.sqrt(6.0 / (a + b)))
+    x = (torch.rand(N, D, generator=gen) * 2 - 1) * bound(N, D) * 30
+    ee = (torch.rand(2 * E, D, generator=gen) * 2 - 1) * bound(2 * E, D) * 100
+    rel = (torch.rand(2 * R, D, generator=gen) * 2 - 1) * bound(2 * R, D) * 3
+    want_ent, want_rel = oracle.layer_forward(sd, 'conv1.', x, ei, ea[0], ee, rel)
+    conv = pkg.MGCNConv(D, O, 2 * R)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items()})
+    conv.to(DEV).eval()
+    with torch.no_grad():
+        got_ent, got_rel = conv(x.to(DEV), ei.to(DEV), ea[0].to(DEV), None, ee.to(DEV), rel.to(DEV))
+    np.testing.assert_allclose(got_ent.cpu().numpy(), want_ent.numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got_rel.cpu().numpy(), want_rel.numpy(), rtol=0, atol=1e-5)
+    assert float(want_ent.abs().mean()) > 0.05            # the comparison is not vacuous
+
+
+def test_cpu_tensors_fail_loudly(pkg):
+    g = golden('toy_small')
+    sd = g.state_dict()
+    csr = pkg.GraphCSR(7, 11, g.t('dl_edge_index'), g.t('dl_edge_attr')[0], DEV)
+    with pytest.raises(pkg._native.NativeError):
+        pkg._native.aggregate_fwd(csr, sd['entity_embedding'], torch.cat([sd['relation_embedding'], sd['conv1.loop_rel']]),
+                                  None, True, None, torch.empty(7, 32))

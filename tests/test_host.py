@@ -1,0 +1,189 @@
+"""CPU-only tests: the C-ABI library loads and exports what include/mgcn_hip.h declares, the host feeder
+(integer work, bit-exact), the loader surface, and the loud failure of the product path without a GPU."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import ALL_CASES, FULL_CASES, GOLDEN, ROOT, golden
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, 'include', 'mgcn_hip.h')).read()
+    declared = set(re.findall(r'\b(mgcn_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(pkg._native.EXPORTS)
+    handle = ctypes.CDLL(pkg._native.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert pkg._native.lib().mgcn_abi_version() == 1
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_feeder_bit_exact(pkg, case):
+    g = golden(case)
+    ei, et = g.t('dl_edge_index'), g.t('dl_edge_attr')[0]
+    N, R, E = int(g['dl_num_entity']), int(g['dl_num_relation']), int(g['dl_num_edge'])
+    h = pkg._native.csr_build_host(N, 2 * R + 1, ei, et)
+    for half in range(2):
+        lo = half * E
+        dst = ei[1, lo:lo + E].numpy()
+        order = np.argsort(dst, kind='stable') + lo                       # (dst, edge id) order
+        assert np.array_equal(h['perm'][lo:lo + E].numpy(), order)
+        assert np.array_equal(h['rowptr'][half].numpy(), np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]))
+        assert np.array_equal(h['rec'][lo:lo + E, 0].numpy(), ei[0].numpy()[order])
+        assert np.array_equal(h['rec'][lo:lo + E, 1].numpy(), et.numpy()[order])
+        assert np.array_equal(h['rec'][lo:lo + E, 3].numpy(), order)
+        assert np.array_equal(h['slot_dst'][lo:lo + E].numpy(), dst[order - lo])
+        src_of_slot = h['rec'][lo:lo + E, 0].numpy()
+        assert np.array_equal(h['srcslots'][lo:lo + E].numpy(), np.argsort(src_of_slot, kind='stable') + lo)
+        assert np.array_equal(h['srcptr'][half].numpy(), np.concatenate([[0], np.cumsum(np.bincount(src_of_slot, minlength=N))]))
+    typ = h['rec'][:, 1].numpy()
+    assert np.array_equal(h['typeslots'].numpy(), np.argsort(typ, kind='stable'))
+    assert np.array_equal(h['typeptr'].numpy(), np.concatenate([[0], np.cumsum(np.bincount(typ, minlength=2 * R + 1))]))
+    norms = h['rec'][:, 2].contiguous().view(torch.float32).numpy()
+    want = np.concatenate([g['norm_in'], g['norm_out']])[h['perm'].numpy()]
+    assert np.array_equal(norms, want)                                    # f32 bit-exact (model.py:72-80)
+
+
+def test_feeder_rejects_bad_input(pkg):
+    ei = torch.tensor([[0, 5], [1, 0]])
+    with pytest.raises(pkg._native.NativeError, match='outside'):
+        pkg._native.csr_build_host(3, 3, ei, torch.tensor([0, 1]))
+    with pytest.raises(pkg._native.NativeError, match='type'):
+        pkg._native.csr_build_host(6, 1, ei, torch.tensor([0, 1]))
+    h = pkg._native.csr_build_host(4, 3, torch.empty((2, 0), dtype=torch.int64), torch.empty(0, dtype=torch.int64))
+    assert h['rowptr'].abs().sum() == 0                                    # empty graph
+
+
+def _loader(pkg, g):
+    cwd = os.getcwd()
+    os.chdir(GOLDEN)
+    try:
+        params = types.SimpleNamespace(**g.hp)
+        return pkg.DataLoader(os.path.basename(g.data_dir), params), params
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_data_loader_matches_reference(pkg, case):
+    g = golden(case)
+    dl, params = _loader(pkg, g)
+    assert (dl.num_entity, dl.num_relation, dl.num_edge) == (int(g['dl_num_entity']), int(g['dl_num_relation']), int(g['dl_num_edge']))
+    assert sorted(dl.entity2id, key=dl.entity2id.get) == list(g['dl_entity_names'])
+    assert sorted(dl.relation2id, key=dl.relation2id.get) == list(g['dl_relation_names'])
+    gr = dl.graph
+    assert np.array_equal(gr.edge_index.numpy(), g['dl_edge_index'])
+    assert np.array_equal(gr.edge_attr.numpy(), g['dl_edge_attr'])
+    assert np.array_equal(gr.edge_norm.numpy(), g['dl_edge_norm'])
+    assert np.array_equal(gr.entity.numpy(), g['dl_entity']) and gr.num_nodes == int(g['dl_num_nodes'])
+    for split in ('train', 'valid_tail', 'valid_head', 'test_tail', 'test_head'):
+        qs = dl.triplets[split]
+        assert np.array_equal(np.array([q['triple'] for q in qs], dtype=np.int64).reshape(-1, 3), g['dl_q_%s_triple' % split])
+        ptr = g['dl_q_%s_label_ptr' % split]
+        idx = g['dl_q_%s_label_idx' % split]
+        for i, q in enumerate(qs):
+            assert sorted(q['label']) == list(idx[ptr[i]:ptr[i + 1]])
+    iters = dl.get_data_loaders(4, 0, params)
+    assert set(iters) == {'train', 'valid_head', 'valid_tail', 'test_head', 'test_tail'}
+    trip, lab = next(iter(iters['valid_tail']))
+    assert trip.dtype == torch.int64 and trip.shape[1] == 3 and lab.shape == (trip.shape[0], dl.num_entity)
+    with pytest.raises(ValueError):
+        dl._get_dataset('nope', params)
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_label_rows_and_smoothing(pkg, case):
+    g = golden(case)
+    dl, params = _loader(pkg, g)
+    ds = dl._get_dataset('train', params)
+    assert np.array_equal(ds[0][1].numpy(), g['smooth_label0'])           # (1-eps)*y + 1/N (Q6)
+    assert ds[0][0].tolist()[2] == -1
+    ev = dl._get_dataset('test_tail', params)
+    row = ev[0][1]
+    assert set(row.unique().tolist()) <= {0.0, 1.0}
+
+
+def test_uppercase_token_raises_like_reference(pkg, tmp_path):
+    d = tmp_path / 'data' / 'u'
+    d.mkdir(parents=True)
+    for split in ('train', 'valid', 'test'):
+        (d / (split + '.txt')).write_text('A\tr\tb')
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        with pytest.raises(KeyError):
+            pkg.DataLoader('u', types.SimpleNamespace(lbl_smooth=0.0))
+    finally:
+        os.chdir(cwd)
+
+
+def test_graph_to_is_in_place(pkg):
+    g = golden('toy_small')
+    dl, _ = _loader(pkg, g)
+    gr = dl.graph
+    assert gr.to('cpu') is gr
+    edge_type, edge_ids = gr.edge_attr                                      # model.py:26 unpacking
+    assert edge_type.shape == edge_ids.shape
+
+
+def test_state_dict_keys_match_reference(pkg):
+    g = golden('toy_small')
+    dl, params = _loader(pkg, g)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    want = set(g.state_dict())
+    assert set(model.state_dict()) == want
+    model.load_state_dict(g.state_dict())                                  # a reference checkpoint loads
+    two = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, types.SimpleNamespace(gcn_layers=2, **g.hp))
+    assert set(two.state_dict()) - want == {k for k in two.state_dict() if 'extra' in k}
+
+
+def test_seeded_init_matches_reference(pkg):
+    """Same construction order and initialisers as the reference (utils.py:113-118, model.py:12-22,49-70,
+    132-157): with the same seed the parameters are identical, so seeded runs are comparable."""
+    g = golden('toy_small')
+    if not g.has('init_sum_entity_embedding'):
+        pytest.skip('golden has no init sums')
+    dl, params = _loader(pkg, g)
+    torch.manual_seed(2020)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    for k, p in model.named_parameters():
+        assert float(p.double().sum()) == float(g['init_sum_' + k]), k
+
+
+def test_product_path_has_no_cpu_fallback(pkg):
+    g = golden('toy_small')
+    dl, params = _loader(pkg, g)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params).eval()
+    trip = g.t('dl_q_test_tail_triple')
+    with torch.no_grad(), pytest.raises(pkg._native.NativeError, match='GPU'):
+        model(trip[:, 0], trip[:, 1], dl.graph)
+
+
+def test_product_does_not_import_oracle():
+    pkg_dir = os.path.join(ROOT, 'kgc-gcn_amd')
+    for fn in os.listdir(pkg_dir):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg_dir, fn)).read()
+            assert 'oracle' not in src.replace('no oracle', ''), fn
+
+
+def test_dropin_module_names(pkg):
+    import sys
+    saved = {k: sys.modules.get(k) for k in ('model', 'data_loader', 'utils')}
+    try:
+        pkg.dropin.install()
+        import data_loader
+        import model
+        import utils
+        assert model.MGCN is pkg.MGCN and data_loader.DataLoader is pkg.DataLoader and hasattr(utils, 'get_param')
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
