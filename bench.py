@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""bench.py — aggregated edges/sec of the full-graph M-GCN encoder forward (+ filtered-MRR eval wall-clock).
+
+Workload (BASELINE.json configs[1]): synthetic graph of the public WN18RR shape (N=40 943, R=11,
+E=86 835 train triples -> 173 670 directed edges + N self loops per layer), 2 layers 100 -> 200 -> 200,
+f32, eval mode. A "step" is one encoder forward over the whole graph: per layer one aggregation launch,
+one f32-MFMA dense+BN+tanh launch and the small relation projection. Inputs (tables, CSR, weights) are
+resident in HBM before the timed region. One JSON line on stdout (rank 0).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 run under torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPES = {  # public dataset shapes
+    'wn18rr': dict(N=40943, R=11, E=86835, n_eval=3134),
+    'fb15k237': dict(N=14541, R=237, E=272115, n_eval=20466),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def synth_graph(shape, seed=0):
+    """Uniform random triples of the given shape (numpy default_rng, duplicates kept), plus the
+    bi-directional edge list exactly as the feeder expects it (data_loader.py:143-149)."""
+    rng = np.random.default_rng(seed)
+    N, R, E = shape['N'], shape['R'], shape['E']
+    s = rng.integers(0, N, size=E)
+    r = rng.integers(0, R, size=E)
+    o = rng.integers(0, N, size=E)
+    edge_index = np.stack((np.concatenate((s, o)), np.concatenate((o, s))))
+    edge_attr = np.stack((np.concatenate((r, r + R)), np.arange(2 * E, dtype=np.int64)))
+    return torch.from_numpy(edge_index), torch.from_numpy(edge_attr)
+
+
+def layer_bytes(N, E2, R2, D, O):
+    """Algorithmic (compulsory) bytes of one layer forward, SURVEY §8(d) / BASELINE.md §3."""
+    return E2 * (4 * D + 8) + 2 * (N + 1) * 4 + 4 * N * D + 4 * (R2 + 1) * D + 16 * D * O + 4 * N * O
+
+
+def agg_kernel_bytes(N, E2, R2, D):
+    """Compulsory bytes of the aggregation launch alone: slot records as laid out (16 B), per-edge rows,
+    row pointers, layer input, relation table, and the [N, 3D] aggregate it writes."""
+    return E2 * (4 * D + 16) + 2 * (N + 1) * 4 + 4 * N * D + 4 * (R2 + 1) * D + 4 * N * 3 * D
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--shape', default='wn18rr', choices=sorted(SHAPES))
+    ap.add_argument('--layers', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eval', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(os.environ.get('MGCN_DIST_BACKEND', 'nccl'), device_id=dev)
+
+    pkg = importlib.import_module('kgc-gcn_amd')
+    shape = SHAPES[args.shape]
+    N, R, E = shape['N'], shape['R'], shape['E']
+    D, O = 100, 200
+    params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=10,
+                                   k_h=20, num_filter=200, kernel_size=7, bias=False, lbl_smooth=0.1,
+                                   gcn_layers=args.layers, cache_encoder=False, device=dev)
+
+    # every rank works on its own graph of the same shape (seed = rank): per-GPU work fixed -> weak scaling
+    edge_index, edge_attr = synth_graph(shape, seed=rank)
+    graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
+    graph.entity = torch.arange(N)
+    graph.num_nodes = N
+    graph.edge_norm = None
+    graph.to(dev)
+    torch.manual_seed(0)
+    model = pkg.MGCN(N, R, E, params)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():                                   # non-trivial BN statistics
+        for layer in [model.conv1] + list(model.conv1_extra):
+            layer.ent_bn.running_mean.copy_(torch.randn(O, generator=g) * 0.05)
+            layer.ent_bn.running_var.copy_(torch.rand(O, generator=g) * 0.5 + 0.05)
+    model.to(dev).eval()
+
+    def step():
+        with torch.no_grad():
+            return model.encode(graph)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    edges_per_step = args.layers * (2 * E + N)               # per rank
+    value = world * edges_per_step * args.steps / elapsed
+    result = {
+        'metric': 'aggregated_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s-shape synthetic graph (N=%d, R=%d, E=%d), %d-layer M-GCN encoder %s, full-graph '
+                               'forward, eval mode' % (args.shape, N, R, E, args.layers,
+                                                       '->'.join(map(str, [D] + [O] * args.layers))),
+                   'edges_per_step_per_gpu': edges_per_step, 'parallelism': 'graph-per-gpu x%d' % world},
+    }
+
+    if rank == 0:
+        result.update(kernel_breakdown(pkg, model, graph, args, N, R, E, D, O))
+        if not args.no_eval:
+            result['eval'] = eval_wallclock(pkg, model, graph, params, shape, dev)
+        if not args.no_cpu_baseline and world == 1:
+            result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O)
+            result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
+    """Per-launch device time of the step's kernels, HIP events on the launch stream, same K steps."""
+    nat = pkg._native
+    csr = graph.csr(2 * R + 1)
+    layers = [model.conv1] + list(model.conv1_extra)
+    tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
+    K = args.steps
+    times = {}
+
+    def timed(name, fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        times[name] = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e3        # us
+
+    with torch.no_grad():
+        x, rel = model.entity_embedding, model.relation_embedding
+        for li, (layer, table) in enumerate(zip(layers, tables)):
+            d = layer.in_channels
+            rels = torch.cat([rel, layer.loop_rel], dim=0)
+            agg = torch.empty((N, 3 * d), device=x.device)
+            out = torch.empty((N, O), device=x.device)
+            bn = layer.ent_bn
+            le = layer.loop_edge.reshape(-1)
+            timed('aggregate_l%d' % (li + 1), lambda: nat.aggregate_fwd(csr, x, rels, table, True, le, agg))
+            timed('dense_l%d' % (li + 1), lambda: nat.dense_bn_tanh_fwd(
+                agg, layer.in_weight, layer.out_weight, layer.loop_weight, layer.bias, bn.running_mean,
+                bn.running_var, bn.weight, bn.bias, bn.eps, out))
+            x, rel = out, nat.matmul(rels, layer.rels_weight)[:-1].contiguous()
+    dims = [D] + [O] * (args.layers - 1)
+    kern = {}
+    for li, d in enumerate(dims):
+        ab = agg_kernel_bytes(N, 2 * E, 2 * R, d)
+        fl = 2.0 * N * 3 * d * O
+        ta, td = times['aggregate_l%d' % (li + 1)], times['dense_l%d' % (li + 1)]
+        kern['aggregate_l%d' % (li + 1)] = {'us': ta, 'algorithmic_bytes': ab, 'GBps': ab / ta / 1e3,
+                                            'hbm_frac': ab / ta / 1e3 / HBM_PEAK_GBS}
+        kern['dense_l%d' % (li + 1)] = {'us': td, 'algorithmic_flops': fl, 'TFLOPs': fl / td / 1e6,
+                                        'mfma_f32_frac': fl / td / 1e6 / MFMA_F32_PEAK_TFLOPS}
+        lb = layer_bytes(N, 2 * E, 2 * R, d, O)
+        kern['layer%d' % (li + 1)] = {'us': ta + td, 'algorithmic_bytes': lb,
+                                      'hbm_frac': lb / (ta + td) / 1e3 / HBM_PEAK_GBS}
+    dom = max((k for k in times), key=lambda k: times[k])
+    if dom.startswith('aggregate'):
+        k = kern[dom]
+        roof = {'kernel': 'agg_fwd_kernel (%s)' % dom, 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': k['hbm_frac'], 'traffic': None}
+    else:
+        k = kern[dom]
+        roof = {'kernel': 'tile_kernel<BN_TANH> (%s)' % dom, 'bound': 'mfma', 'achieved': k['TFLOPs'],
+                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k['mfma_f32_frac'], 'traffic': None}
+    return {'roofline': roof, 'kernels': kern}
+
+
+def eval_wallclock(pkg, model, graph, params, shape, dev):
+    """Full filtered-MRR evaluation wall-clock: 2 x n_eval queries in batches of 128 against all N entities,
+    query blocks and label rows already on the device. `fused` = HIP score+filter+count kernel, encoder computed
+    once (eval-mode cache); `reference_order` = encoder recomputed per batch, [B,N] scores + double argsort."""
+    N = shape['N']
+    n_eval = min(shape['n_eval'], 4096)
+    rng = np.random.default_rng(7)
+    B = 128
+    batches = []
+    for side in range(2):
+        for i in range(0, n_eval, B):
+            b = min(B, n_eval - i)
+            trip = torch.from_numpy(np.stack((rng.integers(0, N, b), rng.integers(0, 2 * shape['R'], b),
+                                              rng.integers(0, N, b)), axis=1)).to(dev)
+            lab = torch.zeros((b, N), device=dev)
+            extra = torch.from_numpy(rng.integers(0, N, (b, 4))).to(dev)
+            lab.scatter_(1, extra, 1.0)
+            lab.scatter_(1, trip[:, 2:3], 1.0)
+            batches.append((trip, lab))
+    out = {'queries': 2 * n_eval, 'batch': B}
+    with torch.no_grad():                                   # warm every code path once (MIOpen find, code load)
+        trip, lab = batches[0]
+        model.rank_counts(trip[:, 0], trip[:, 1], trip[:, 2].contiguous(), lab, graph)
+        pkg.harness.ranks_from_scores(model(trip[:, 0], trip[:, 1], graph), lab, trip[:, 2])
+    for name, fused, cache in (('fused_cached_s', True, True), ('fused_recompute_s', True, False),
+                               ('reference_order_s', False, False)):
+        params.cache_encoder = cache
+        model._enc_cache = None
+        mrr = 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            acc = torch.zeros((), dtype=torch.float64, device=dev)
+            for trip, lab in batches:
+                if fused:
+                    counts, _ = model.rank_counts(trip[:, 0], trip[:, 1], trip[:, 2].contiguous(), lab, graph)
+                    ranks = 1 + counts[:, 0] + counts[:, 1]
+                else:
+                    ranks = pkg.harness.ranks_from_scores(model(trip[:, 0], trip[:, 1], graph), lab, trip[:, 2])
+                acc += (1.0 / ranks.double()).sum()
+            mrr = float(acc.item()) / (2 * n_eval)
+        torch.cuda.synchronize()
+        out[name] = time.perf_counter() - t0
+        out[name.replace('_s', '_mrr')] = mrr
+    params.cache_encoder = False
+    model._enc_cache = None
+    return out
+
+
+def host_cores():
+    """Cores this process may actually use: cgroup quota, then affinity, then cpu_count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get('MGCN_CPU_THREADS', min(n, 16)))   # a 1-GPU box's CPU share is 16
+
+
+def cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O):
+    """The oracle (CPU restatement in the reference's order of operations: per-edge weight multiply, identity
+    gathers, norms recomputed per call) on this box's host cores, same graph and parameters, bounded sample."""
+    oracle = importlib.import_module('oracle.mgcn_oracle')
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    prefixes = ['conv1.'] + ['conv1_extra.%d.' % i for i in range(args.layers - 1)]
+    tables = ['edge_embeddings'] + ['edge_embeddings_extra.%d' % i for i in range(args.layers - 1)]
+
+    def cpu_step():
+        x, rel = sd['entity_embedding'].index_select(0, torch.arange(N)), sd['relation_embedding']
+        for pre, tab in zip(prefixes, tables):
+            ee = sd[tab].index_select(0, edge_attr[1])
+            x, rel = oracle.layer_forward(sd, pre, x, edge_index, edge_attr[0], ee, rel)
+        return x
+
+    with torch.no_grad():
+        cpu_step()
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 20 and (time.perf_counter() - t_start < 20.0 or len(times) < 3):
+            t0 = time.perf_counter()
+            cpu_step()
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {'value': args.layers * (2 * E + N) / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full-graph %d-layer forwards of the same workload (min of %d, %.1f ms each)'
+                      % (len(times), args.layers, len(times), best * 1e3)}
+
+
+if __name__ == '__main__':
+    main()
