@@ -154,39 +154,49 @@ def main():
 
 
 def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
-    """Per-launch device time of the step's kernels, HIP events on the launch stream, same K steps."""
+    """Per-launch device time of the step's kernels, measured IN SEQUENCE (the same launches, order and
+    operands as model.encode, so caches hold what they hold in the real step) with HIP events recorded on the
+    launch stream between the kernels, over the same K steps."""
     nat = pkg._native
     csr = graph.csr(2 * R + 1)
     layers = [model.conv1] + list(model.conv1_extra)
     tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
     K = args.steps
-    times = {}
+    names = []
+    for li in range(len(layers)):
+        names += ['aggregate_l%d' % (li + 1), 'dense_l%d' % (li + 1), 'relproj_l%d' % (li + 1)]
+    bufs = []
+    for layer in layers:
+        bufs.append((torch.empty((N, 3 * layer.in_channels), device=model.entity_embedding.device),
+                     torch.empty((N, O), device=model.entity_embedding.device), layer.stacked_weight()))
 
-    def timed(name, fn):
-        fn()
-        torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-        for a, b in ev:
-            a.record()
-            fn()
-            b.record()
-        torch.cuda.synchronize()
-        times[name] = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e3        # us
-
-    with torch.no_grad():
+    def sequence(events):
         x, rel = model.entity_embedding, model.relation_embedding
-        for li, (layer, table) in enumerate(zip(layers, tables)):
-            d = layer.in_channels
-            rels = torch.cat([rel, layer.loop_rel], dim=0)
-            agg = torch.empty((N, 3 * d), device=x.device)
-            out = torch.empty((N, O), device=x.device)
+        i = 0
+        for layer, table, (agg, out, wcat) in zip(layers, tables, bufs):
             bn = layer.ent_bn
-            le = layer.loop_edge.reshape(-1)
-            timed('aggregate_l%d' % (li + 1), lambda: nat.aggregate_fwd(csr, x, rels, table, True, le, agg))
-            timed('dense_l%d' % (li + 1), lambda: nat.dense_bn_tanh_fwd(
-                agg, layer.in_weight, layer.out_weight, layer.loop_weight, layer.bias, bn.running_mean,
-                bn.running_var, bn.weight, bn.bias, bn.eps, out))
-            x, rel = out, nat.matmul(rels, layer.rels_weight)[:-1].contiguous()
+            events[i].record(); i += 1
+            nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1))
+            events[i].record(); i += 1
+            nat.dense_bn_tanh_fwd(agg, wcat, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
+            events[i].record(); i += 1
+            rel = nat.matmul(rel, layer.rels_weight)
+            x = out
+        events[i].record()
+
+    nev = 3 * len(layers) + 1
+    with torch.no_grad():
+        sequence([torch.cuda.Event(enable_timing=True) for _ in range(nev)])
+        torch.cuda.synchronize()
+        all_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(K)]
+        for ev in all_ev:
+            sequence(ev)
+        torch.cuda.synchronize()
+    times = {}
+    for li in range(len(layers)):
+        for j, kind in enumerate(('aggregate', 'dense', 'relproj')):
+            idx = 3 * li + j
+            times['%s_l%d' % (kind, li + 1)] = float(np.mean([ev[idx].elapsed_time(ev[idx + 1]) for ev in all_ev])) * 1e3
     dims = [D] + [O] * (args.layers - 1)
     kern = {}
     for li, d in enumerate(dims):
@@ -200,6 +210,9 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
         lb = layer_bytes(N, 2 * E, 2 * R, d, O)
         kern['layer%d' % (li + 1)] = {'us': ta + td, 'algorithmic_bytes': lb,
                                       'hbm_frac': lb / (ta + td) / 1e3 / HBM_PEAK_GBS}
+    for k in times:
+        if k.startswith('relproj'):
+            kern[k] = {'us': times[k]}
     dom = max((k for k in times), key=lambda k: times[k])
     if dom.startswith('aggregate'):
         k = kern[dom]

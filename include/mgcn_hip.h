@@ -80,17 +80,21 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
  * multiply moved after the sum:
  *   A[n, 0:D)   = sum over in-half  slots p of n:  norm_p * ((x[src_p] * rel[type_p]) * ee_p)
  *   A[n, D:2D)  = same over the out-half
- *   A[n, 2D:3D) = (x[n] * rel[num_rel_rows-1]) * loop_edge            (self loop, no norm)
+ *   A[n, 2D:3D) = (x[n] * loop_rel) * loop_edge                       (self loop, no norm)
+ * The relation table has num_rel_rows rows: rows [0, num_rel_rows-1) at rel_dev, the last (self-loop)
+ * row at loop_rel_dev [D] — two pointers so the caller needs no concatenation (model.py:86); they may
+ * point into one contiguous [num_rel_rows, D] tensor.
  * Slots of one destination are summed in slot order by one lane group: no atomics, bitwise
  * reproducible. `ee_dev` is the per-edge table: in SLOT order if ee_in_slot_order != 0 (streamed),
  * else in reference edge-id order (gathered through rec.eid); NULL = no per-edge factor.
- *   x_dev [N, D] (ldx floats between rows), rel_dev [num_rel_rows, D], loop_edge_dev [D] or NULL
+ *   x_dev [N, D] (ldx floats between rows), rel_dev [num_rel_rows-1, D], loop_edge_dev [D] or NULL
  *   (then the third block is not written and A needs only 2D columns), a_dev [N, lda].
  */
 int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                        const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
-                       int64_t ldx, const float *rel_dev, const float *ee_dev, int32_t ee_in_slot_order,
-                       const float *loop_edge_dev, float *a_dev, int64_t lda, void *stream);
+                       int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
+                       int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
+                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) Aggregation backward (autograd through (2); driven by main.py:66). Given g = dL/dA [N, lda]
@@ -116,10 +120,10 @@ size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t
  * model.py:103-106 in eval mode:
  *   out = tanh( BN_eval( (A[:,0:D) W_in + A[:,D:2D) W_out + A[:,2D:3D) W_loop) / 3 + bias ) )
  * BN_eval(v) = (v - mean) / sqrt(var + eps) * gamma + beta. bias_dev may be NULL.
+ * w_dev [3*dim_in, dim_out] = W_in, W_out, W_loop stacked by rows (one contiguous matrix).
  */
 int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, const float *a_dev, int64_t lda,
-                           const float *w_in_dev, const float *w_out_dev, const float *w_loop_dev,
-                           const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev,
+                           const float *w_dev, const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev,
                            const float *bn_gamma_dev, const float *bn_beta_dev, float bn_eps,
                            float *out_dev, int64_t ldo, void *stream);
 

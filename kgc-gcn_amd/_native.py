@@ -21,12 +21,12 @@ _SIGNATURES = {
     'mgcn_abi_version': (ctypes.c_int, []),
     'mgcn_last_error': (ctypes.c_char_p, []),
     'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64] + [_ptr] * 10),
-    'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _i32,
+    'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                           _ptr, _ptr, _i64, _ptr]),
     'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _i64,
                                           _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
-    'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 8 + [_f32, _ptr, _i64, _ptr]),
+    'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
@@ -115,11 +115,17 @@ def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward
     return out
 
 
-def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out):
-    """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR."""
+def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None):
+    """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR.
+    `rel` is either the whole relation table [num_rel_rows, D] (last row = self-loop row) or, with
+    `loop_rel` [D] given separately, its first num_rel_rows-1 rows (no concatenation needed)."""
     N, E, D = csr.num_nodes, csr.num_edges_half, x.size(1)
-    _same_device(csr.rowptr, x, rel, ee, loop_edge, out)
-    if x.size(0) != N or rel.size(0) != csr.num_rel_rows or rel.size(1) != D:
+    _same_device(csr.rowptr, x, rel, ee, loop_edge, out, loop_rel)
+    if loop_rel is None:
+        if rel.size(0) != csr.num_rel_rows:
+            raise NativeError('aggregate_fwd: rel has %d rows, graph expects %d' % (rel.size(0), csr.num_rel_rows))
+        loop_rel, rel = rel[-1], rel[:-1]
+    if x.size(0) != N or rel.size(0) != csr.num_rel_rows - 1 or rel.size(1) != D or loop_rel.numel() != D:
         raise NativeError('aggregate_fwd: x %s / rel %s do not match graph (N=%d, rel rows=%d)'
                           % (tuple(x.shape), tuple(rel.shape), N, csr.num_rel_rows))
     if ee is not None and tuple(ee.shape) != (2 * E, D):
@@ -133,7 +139,7 @@ def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out):
         raise NativeError('aggregate_fwd: out %s too small for (%d, %d)' % (tuple(out.shape), N, modes * D))
     _check(lib().mgcn_aggregate_fwd(
         N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
-        _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'),
+        _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
         _dev(out, torch.float32, 'out'), _ld(out), _stream(x)), 'mgcn_aggregate_fwd')
     return out
@@ -167,24 +173,24 @@ def aggregate_bwd(csr, x, rel, ee, g, want_gx=True, want_gee=True, want_grel=Tru
     return gx, gee, grel
 
 
-def dense_bn_tanh_fwd(a, w_in, w_out, w_loop, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, out):
-    """(4) out = tanh(BN_eval((A [W_in; W_out; W_loop]) / 3 + bias))."""
-    N, D, O = a.size(0), w_in.size(0), w_in.size(1)
-    _same_device(a, w_in, w_out, w_loop, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
-    for w in (w_in, w_out, w_loop):
-        if tuple(w.shape) != (D, O) or not w.is_contiguous():
-            raise NativeError('dense_bn_tanh_fwd: weights must be contiguous (%d, %d)' % (D, O))
+def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, out):
+    """(4) out = tanh(BN_eval((A @ w_cat) / 3 + bias)), w_cat [3D, O] = W_in, W_out, W_loop stacked by rows."""
+    N, O = a.size(0), w_cat.size(1)
+    D = w_cat.size(0) // 3
+    _same_device(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
+    if w_cat.dim() != 2 or w_cat.size(0) != 3 * D or not w_cat.is_contiguous():
+        raise NativeError('dense_bn_tanh_fwd: w_cat must be contiguous (3D, O)')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:
             raise NativeError('dense_bn_tanh_fwd: per-column vectors must have %d elements' % O)
     if a.size(1) < 3 * D or tuple(out.shape) != (N, O):
         raise NativeError('dense_bn_tanh_fwd: a %s / out %s do not match' % (tuple(a.shape), tuple(out.shape)))
     _check(lib().mgcn_dense_bn_tanh_fwd(
-        N, D, O, _dev(a, torch.float32, 'a'), _ld(a), _dev(w_in, torch.float32, 'w_in'),
-        _dev(w_out, torch.float32, 'w_out'), _dev(w_loop, torch.float32, 'w_loop'), _dev(bias, torch.float32, 'bias', True),
-        _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
-        _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
-        _dev(out, torch.float32, 'out'), _ld(out), _stream(a)), 'mgcn_dense_bn_tanh_fwd')
+        N, D, O, _dev(a, torch.float32, 'a'), _ld(a), _dev(w_cat, torch.float32, 'w_cat'),
+        _dev(bias, torch.float32, 'bias', True), _dev(bn_mean, torch.float32, 'bn_mean'),
+        _dev(bn_var, torch.float32, 'bn_var'), _dev(bn_gamma, torch.float32, 'bn_gamma'),
+        _dev(bn_beta, torch.float32, 'bn_beta'), float(eps), _dev(out, torch.float32, 'out'), _ld(out), _stream(a)),
+        'mgcn_dense_bn_tanh_fwd')
     return out
 
 

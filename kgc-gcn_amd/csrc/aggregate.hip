@@ -47,16 +47,19 @@ struct AggArgs {
   const int32_t *rowptr;  // [2][N+1]
   const int4 *rec;        // [2E] {src, type, norm bits, eid}
   const float *x;
-  const float *rel;
-  const float *ee;  // may be null
+  const float *rel;       // rows [0, rel_rows-1)
+  const float *loop_rel;  // row rel_rows-1
+  const float *ee;        // may be null
   const float *loop_edge;
   float *a;
   int64_t ldx, lda;
   int32_t n, e, d, rel_rows, ee_slot_order, modes;
 };
 
-// GS lanes per group (power of two <= 64), CPL column chunks per lane.
-template <int VEC, int CPL>
+// GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots in flight per group:
+// all of a batch's record loads are issued first, then all 3*U row loads, then the arithmetic, so a
+// short segment (WN18RR: 2.1 slots on average) costs three dependent memory round trips in total.
+template <int VEC, int CPL, int U>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   using V = Vec<VEC>;
   using T = typename V::type;
@@ -68,39 +71,60 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   const int node = int(item - int64_t(mode) * p.n);
   const int nchunk = p.d / VEC;
 
-  T acc[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-
   if (mode == 2) {  // self loop: (x * rel[last]) * loop_edge, model.py:91-94,101
     const float *xr = p.x + int64_t(node) * p.ldx;
-    const float *rr = p.rel + int64_t(p.rel_rows - 1) * p.d;
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       const int ch = lane_in_group + c * gs;
       if (ch < nchunk)
         V::store(p.a + int64_t(node) * p.lda + 2 * p.d + ch * VEC,
-                 V::mul(V::mul(V::load(xr + ch * VEC), V::load(rr + ch * VEC)), V::load(p.loop_edge + ch * VEC)));
+                 V::mul(V::mul(V::load(xr + ch * VEC), V::load(p.loop_rel + ch * VEC)), V::load(p.loop_edge + ch * VEC)));
     }
     return;
   }
 
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
   const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);
   const int beg = rp[node], end = rp[node + 1];
   const int64_t base = int64_t(mode) * p.e;
-  for (int s = beg; s < end; ++s) {
-    const int4 r = p.rec[base + s];
-    const float w = __int_as_float(r.z);
-    const float *xr = p.x + int64_t(r.x) * p.ldx;
-    const float *rr = p.rel + int64_t(r.y) * p.d;
-    const float *er = p.ee ? p.ee + (p.ee_slot_order ? (base + s) : int64_t(r.w)) * p.d : nullptr;
+  for (int s = beg; s < end; s += U) {
+    int4 r[U];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      const int ch = lane_in_group + c * gs;
-      if (ch < nchunk) {
-        T m = V::mul(V::load(xr + ch * VEC), V::load(rr + ch * VEC));
-        if (er) m = V::mul(m, V::load(er + ch * VEC));
-        acc[c] = V::add(acc[c], V::muls(m, w));
+    for (int u = 0; u < U; ++u)
+      if (s + u < end) r[u] = p.rec[base + s + u];
+    T xv[U][CPL], rv[U][CPL], ev[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u >= end) continue;
+      const float *xr = p.x + int64_t(r[u].x) * p.ldx;
+      const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
+      const int64_t slot = base + s + u;
+      const float *er = p.ee ? p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d : nullptr;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane_in_group + c * gs;
+        if (ch < nchunk) {
+          xv[u][c] = V::load(xr + ch * VEC);
+          rv[u][c] = V::load(rr + ch * VEC);
+          if (er) ev[u][c] = V::load(er + ch * VEC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u < end) {
+        const float w = __int_as_float(r[u].z);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = lane_in_group + c * gs;
+          if (ch < nchunk) {
+            T m = V::mul(xv[u][c], rv[u][c]);
+            if (p.ee) m = V::mul(m, ev[u][c]);
+            acc[c] = V::add(acc[c], V::muls(m, w));
+          }
+        }
       }
     }
   }
@@ -320,19 +344,21 @@ bool pick_geometry(int d, bool all_aligned, Geometry *g) {
 
 extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                                   const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
-                                  int64_t ldx, const float *rel_dev, const float *ee_dev, int32_t ee_in_slot_order,
-                                  const float *loop_edge_dev, float *a_dev, int64_t lda, void *stream) {
+                                  int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
+                                  int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
+                                  void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_fwd: bad sizes");
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "aggregate_fwd: sizes exceed int32");
-  MGCN_REQUIRE(rowptr_dev && x_dev && rel_dev && a_dev, "aggregate_fwd: null pointer");
+  MGCN_REQUIRE(rowptr_dev && x_dev && a_dev && loop_rel_dev && (rel_dev || num_rel_rows == 1),
+               "aggregate_fwd: null pointer");
   MGCN_REQUIRE(num_edges_half == 0 || rec_dev, "aggregate_fwd: null rec");
   const int modes = loop_edge_dev ? 3 : 2;
   MGCN_REQUIRE(ldx >= dim && lda >= int64_t(modes) * dim, "aggregate_fwd: ldx/lda too small");
   if (num_nodes == 0) return MGCN_OK;
-  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(a_dev) &&
-                       (!ee_dev || mgcn::aligned16(ee_dev)) && (!loop_edge_dev || mgcn::aligned16(loop_edge_dev)) &&
-                       ldx % 4 == 0 && lda % 4 == 0;
+  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
+                       mgcn::aligned16(a_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
+                       (!loop_edge_dev || mgcn::aligned16(loop_edge_dev)) && ldx % 4 == 0 && lda % 4 == 0;
   Geometry g;
   if (!pick_geometry(dim, aligned, &g)) return mgcn::fail(MGCN_EUNSUPPORTED, "aggregate_fwd: dim %d too wide", dim);
   AggArgs p;
@@ -340,6 +366,7 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.x = x_dev;
   p.rel = rel_dev;
+  p.loop_rel = loop_rel_dev;
   p.ee = ee_dev;
   p.loop_edge = loop_edge_dev;
   p.a = a_dev;
@@ -351,7 +378,28 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   p.rel_rows = num_rel_rows;
   p.ee_slot_order = ee_in_slot_order;
   p.modes = modes;
-  MGCN_LAUNCH_GEOM(agg_fwd_kernel, p, int64_t(modes) * num_nodes, g, stream);
+  {
+    const int64_t threads = (int64_t(modes) * num_nodes) << g.gs_log2;
+    const unsigned grid = unsigned((threads + 255) / 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define MGCN_FWD_CASE(V_, C_, U_) hipLaunchKernelGGL((agg_fwd_kernel<V_, C_, U_>), dim3(grid), dim3(256), 0, st, p, g.gs_log2)
+    if (g.vec == 4) {
+      switch (g.cpl) {
+        case 1: MGCN_FWD_CASE(4, 1, 4); break;
+        case 2: MGCN_FWD_CASE(4, 2, 2); break;
+        case 4: MGCN_FWD_CASE(4, 4, 1); break;
+        default: MGCN_FWD_CASE(4, 8, 1); break;
+      }
+    } else {
+      switch (g.cpl) {
+        case 1: MGCN_FWD_CASE(1, 1, 4); break;
+        case 2: MGCN_FWD_CASE(1, 2, 2); break;
+        case 4: MGCN_FWD_CASE(1, 4, 1); break;
+        default: MGCN_FWD_CASE(1, 8, 1); break;
+      }
+    }
+#undef MGCN_FWD_CASE
+  }
   MGCN_CHECK_LAUNCH("agg_fwd_kernel");
   return MGCN_OK;
 }

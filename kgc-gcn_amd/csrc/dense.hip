@@ -1,13 +1,23 @@
 // f32 MFMA tile kernel (v_mfma_f32_16x16x4_f32: exact f32, a k-ordered fma chain) with the fused
 // epilogues of the M-GCN hot path (gfx950):
-//   EPI_NONE      C = A B                                  (relation projection, model.py:107)
+//   EPI_NONE      C = A B
 //   EPI_BN_TANH   out = tanh(BN_eval((A [W_in;W_out;W_loop]) / 3 + bias))   (model.py:103-106,116)
 //   EPI_SIGMOID   score[b, n] = sigmoid(ent[n,:] . x[b,:] + bias[n])        (model.py:177-179)
 //   EPI_TARGET    target[b]   = score[b, obj[b]]  (same tile arithmetic, gathered rows, diagonal)
 //   EPI_RANK      filtered counts gt / ties_lower / ties per query, scores never stored (main.py:122-126)
-// The streamed operand (aggregates [N,3D] or the entity table [N,O]) is always the MFMA A operand; the
-// small operand (weights, or the query block x, read transposed) is B. Block = 4 waves, tile 64 x 64,
-// K slabs of 16 through LDS; each wave owns a 16-row strip and four 16x16 accumulators.
+//
+// Geometry. The streamed operand (aggregates [N,3D], or the entity table [N,O]) is always the MFMA A
+// operand and goes global -> registers directly: lane (r = l&15, q = l>>4) loads the 16 bytes
+// A[row r][16t+4q .. 16t+4q+3] of k-block t, so element i of that float4 is the A fragment of MFMA step
+// i (k = 16t + 4q + i). The small operand B (the weights, or the query block read transposed) is staged
+// through LDS in double-buffered slabs of 16 k-rows shared by the block's two waves; a lane's B fragment
+// of step i is Bs[4q+i][16*tile + (l&15)] (row stride == 4 mod 8 floats -> conflict-free ds_read_b32).
+// Block = 4 waves = 32 rows x NT column tiles: wave w owns row tile (w & 1) and column tiles
+// [ (w>>1)*ceil(NT/2), ... ), i.e. 7 + 6 of the 13 tiles of O = 200, so a wave needs only 28 accumulator
+// registers and five blocks (20 waves, 5 per SIMD) are resident per CU; the WN18RR grid is 1280 blocks =
+// exactly 5 per CU, 2.5 wave-tiles of MFMA work per SIMD with no tail quantisation.
+// Summation order per output element is fixed (k-blocks ascending, step i, then q) and independent of
+// the tile position, so a score computed by TARGET, SIGMOID and RANK is the same f32 value.
 #include <hip/hip_runtime.h>
 
 #include "mgcn_common.h"
@@ -20,8 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct TileArgs {
   const float *a;        // [M, K], row stride lda (EPI_TARGET: row i is a[(obj[i]-row0)*lda])
-  const float *b[3];     // NN: K rows split over up to 3 matrices of `ksplit` rows, row stride ldb
-                         // NT: b[0] = x [ncols, K], row stride ldb
+  const float *b;        // NN: [K, ncols] row stride ldb; NT: x [ncols, K], row stride ldb
   float *c;              // output (NONE / BN_TANH: [M, ldc]; SIGMOID: [ncols, ldc] transposed store)
   const float *bias;     // BN_TANH: [ncols] or null; scoring: [M] per entity
   const float *bn_mean, *bn_var, *bn_gamma, *bn_beta;
@@ -31,132 +40,173 @@ struct TileArgs {
   const float *label;    // RANK: [ncols, ldl]
   unsigned long long *counts;  // RANK: [ncols, 3]
   int64_t lda, ldb, ldc, ldl, m, row0, n_local;
-  int32_t k, ncols, ksplit, tiles_m, tiles_n;
+  int32_t k, ncols, tiles_m;
   int32_t a_vec, b_vec;  // 16-byte loads allowed (alignment + leading dimension checked on the host)
   float bn_eps;
 };
 
-constexpr int BM = 64, BN = 64, BK = 16;
-constexpr int LDAS = BK + 1;   // A tile [BM][LDAS]
-constexpr int LDBS = BN + 16;  // B tile [BK][LDBS]: rows 16 banks apart -> conflict-free fragment reads
+constexpr int WAVES = 4, BM = 32, KS = 16, THREADS = 64 * WAVES;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
-template <int EPI, bool B_NT>
-__global__ __launch_bounds__(256) void tile_kernel(TileArgs p) {
-  __shared__ float As[BM * LDAS];
-  __shared__ float Bs[BK * LDBS];
-  __shared__ unsigned int cnt[EPI == EPI_RANK ? BN * 3 : 1];
+// tanh through one exp and one division: |err| <= ~1e-7 absolute (the layer output feeds a 1e-5-level parity bar);
+// libm's tanhf costs ~60 instructions per element and dominated the epilogue.
+__device__ __forceinline__ float tanhf_(float v) {
+  const float t = __expf(-2.0f * fabsf(v));
+  return copysignf((1.0f - t) / (1.0f + t), v);
+}
+
+// FAST = every operand 16-byte aligned with leading dimensions, K and the column count multiples of 4:
+// one predicated dwordx4 per slot, no scalar tails (the branch-free hot instantiation). !FAST = element-wise
+// guarded loads for arbitrary shapes; same arithmetic, same summation order.
+template <bool FAST>
+__device__ __forceinline__ float4 load4(const float *ptr, bool ok, int first, int limit) {
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (FAST) {
+    if (ok && first < limit) t = *reinterpret_cast<const float4 *>(ptr);
+  } else if (ok) {
+    if (first + 0 < limit) t.x = ptr[0];
+    if (first + 1 < limit) t.y = ptr[1];
+    if (first + 2 < limit) t.z = ptr[2];
+    if (first + 3 < limit) t.w = ptr[3];
+  }
+  return t;
+}
+
+template <bool B_NT, int NT, bool FAST>
+struct BStage {
+  static constexpr int BNC = NT * 16;
+  static constexpr int LDB = BNC + 4;
+  // NN: slots of 4 consecutive columns of one k-row; NT: slots of 4 consecutive k of one column
+  static constexpr int SLOTS = B_NT ? BNC * 4 : KS * (BNC / 4);
+  static constexpr int PER_THREAD = (SLOTS + THREADS - 1) / THREADS;
+  float4 v[PER_THREAD];
+
+  __device__ __forceinline__ void load(const TileArgs &p, int kb, int c0, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      const int s = tid + j * THREADS;
+      if (B_NT) {
+        const int c = s >> 2, kk = kb * KS + (s & 3) * 4;
+        v[j] = load4<FAST>(p.b + int64_t(c0 + c) * p.ldb + kk, s < SLOTS && c0 + c < p.ncols, kk, p.k);
+      } else {
+        const int r = s / (BNC / 4), cc = c0 + (s % (BNC / 4)) * 4;
+        const int kk = kb * KS + r;
+        v[j] = load4<FAST>(p.b + int64_t(kk) * p.ldb + cc, s < SLOTS && kk < p.k, cc, p.ncols);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float *bs, int tid) const {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      const int s = tid + j * THREADS;
+      if (s < SLOTS) {
+        if (B_NT) {
+          const int c = s >> 2, r = (s & 3) * 4;
+          bs[(r + 0) * LDB + c] = v[j].x;
+          bs[(r + 1) * LDB + c] = v[j].y;
+          bs[(r + 2) * LDB + c] = v[j].z;
+          bs[(r + 3) * LDB + c] = v[j].w;
+        } else {
+          const int r = s / (BNC / 4), c = (s % (BNC / 4)) * 4;
+          *reinterpret_cast<float4 *>(bs + r * LDB + c) = v[j];
+        }
+      }
+    }
+  }
+};
+
+template <int EPI, bool B_NT, int NT, bool FAST>
+__global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
+  using Stage = BStage<B_NT, NT, FAST>;
+  constexpr int BNC = Stage::BNC, LDB = Stage::LDB;
+  constexpr int NTW = (NT + 1) / 2;  // column tiles of a wave in the first half; the second half has NT - NTW
+  __shared__ __attribute__((aligned(16))) float Bs[2 * KS * LDB];
+  static_assert(2 * KS == BM, "the output staging tile [BM][LDB] reuses the two slab buffers");
+  __shared__ unsigned int cnt[EPI == EPI_RANK ? BNC * 3 : 1];
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int rt = wave & 1, ch = wave >> 1;
+  const int ct0 = ch * NTW;                      // first column tile of this wave
+  const int nct = ch == 0 ? NTW : NT - NTW;      // wave-uniform
   const int fr = lane & 15, fq = lane >> 4;
-
-  // RANK walks several row tiles per block (grid-stride) and keeps its counts on chip.
-  const int tn = (EPI == EPI_RANK) ? int(blockIdx.y) : int(blockIdx.x / p.tiles_m);
-  const int tm_first = (EPI == EPI_RANK) ? int(blockIdx.x) : int(blockIdx.x % p.tiles_m);
-  const int tm_step = (EPI == EPI_RANK) ? int(gridDim.x) : p.tiles_m;
-  const int c0 = tn * BN;
+  const int c0 = int(blockIdx.y) * BNC;
+  const int nkb = (p.k + KS - 1) / KS;
 
   if (EPI == EPI_RANK) {
-    for (int i = tid; i < BN * 3; i += 256) cnt[i] = 0;
+    for (int i = tid; i < BNC * 3; i += THREADS) cnt[i] = 0;
   }
-  unsigned int my_gt[4] = {0, 0, 0, 0}, my_tl[4] = {0, 0, 0, 0}, my_ti[4] = {0, 0, 0, 0};
-
-  const bool a_vec = p.a_vec != 0, b_vec = p.b_vec != 0;
-
-  for (int tm = tm_first; tm < p.tiles_m; tm += tm_step) {
-    const int64_t r0 = int64_t(tm) * BM;
-    f32x4 acc[4];
+  unsigned int my_gt[NTW], my_tl[NTW], my_ti[NTW];
+  if (EPI == EPI_RANK) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTW; ++t) my_gt[t] = my_tl[t] = my_ti[t] = 0;
+  }
 
-    // the A row this thread stages: row tid/4 of the tile, k quad (tid%4)*4
-    const int ar = tid >> 2, akq = (tid & 3) * 4;
-    int64_t arow = r0 + ar;
-    bool arow_ok = arow < p.m;
-    if (EPI == EPI_TARGET && arow_ok) {
-      const int64_t o = p.obj[arow] - p.row0;   // gathered entity row of query `arow`
-      arow_ok = o >= 0 && o < p.n_local;
+  // RANK walks several row tiles per block (grid-stride) so that its counts stay on chip
+  for (int tm = blockIdx.x; tm < p.tiles_m; tm += gridDim.x) {
+    const int64_t r0 = int64_t(tm) * BM;
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int64_t arow = r0 + rt * 16 + fr;
+    bool a_ok = arow < p.m;
+    if (EPI == EPI_TARGET && a_ok) {
+      const int64_t o = p.obj[arow] - p.row0;  // the entity row query `arow` must be scored against
+      a_ok = o >= 0 && o < p.n_local;
       arow = o;
     }
-    const float *aptr = p.a + (arow_ok ? arow : 0) * p.lda;
+    const float *aptr = p.a + (a_ok ? arow : 0) * p.lda;
 
-    for (int k0 = 0; k0 < p.k; k0 += BK) {
-      // ---- stage A tile ------------------------------------------------------------------
-      {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int kk = k0 + akq;
-        if (arow_ok) {
-          if (a_vec && kk + 3 < p.k) {
-            const float4 t = *reinterpret_cast<const float4 *>(aptr + kk);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (kk + i < p.k) v[i] = aptr[kk + i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) As[ar * LDAS + akq + i] = v[i];
+    Stage st;
+    st.load(p, 0, c0, tid);
+    float4 a_cur = load4<FAST>(aptr + 4 * fq, a_ok, 4 * fq, p.k);
+    __syncthreads();  // previous tile's readers are done with buffer 0
+    st.store(Bs, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+      float4 a_next = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool more = kb + 1 < nkb;
+      if (more) {
+        st.load(p, kb + 1, c0, tid);
+        a_next = load4<FAST>(aptr + (kb + 1) * KS + 4 * fq, a_ok, (kb + 1) * KS + 4 * fq, p.k);
       }
-      // ---- stage B tile ------------------------------------------------------------------
-      if (B_NT) {  // Bs[k][c] = x[c0 + c][k0 + k]
-        const int bc = tid >> 2, bkq = (tid & 3) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int kk = k0 + bkq;
-        if (c0 + bc < p.ncols) {
-          const float *bp = p.b[0] + int64_t(c0 + bc) * p.ldb;
-          if (b_vec && kk + 3 < p.k) {
-            const float4 t = *reinterpret_cast<const float4 *>(bp + kk);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
+      const float *bs = Bs + cur * KS * LDB + (4 * fq) * LDB + ct0 * 16 + fr;
+      const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+      // B fragments one MFMA step ahead: the ds_reads of step i+1 are in flight under step i's MFMAs
+      float bf[2][NTW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (kk + i < p.k) v[i] = bp[kk + i];
-          }
+      for (int t = 0; t < NTW; ++t) bf[0][t] = bs[t * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i + 1 < 4) {
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) bf[(i + 1) & 1][t] = bs[(i + 1) * LDB + t * 16];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[(bkq + i) * LDBS + bc] = v[i];
-      } else {  // Bs[k][c] = W_{(k0+k)/ksplit}[(k0+k)%ksplit][c0 + c]
-        const int bk = tid >> 4, bcq = (tid & 15) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int kk = k0 + bk;
-        if (kk < p.k) {
-          const int seg = kk / p.ksplit;
-          const float *bp = p.b[seg] + int64_t(kk - seg * p.ksplit) * p.ldb;
-          const int cc = c0 + bcq;
-          if (b_vec && cc + 3 < p.ncols) {
-            const float4 t = *reinterpret_cast<const float4 *>(bp + cc);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (cc + i < p.ncols) v[i] = bp[cc + i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Bs[bk * LDBS + bcq + i] = v[i];
+        for (int t = 0; t < NTW; ++t)
+          if (t < nct) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bf[i & 1][t], acc[t], 0, 0, 0);
       }
+      if (more) st.store(Bs + (cur ^ 1) * KS * LDB, tid);
+      a_cur = a_next;
       __syncthreads();
-      // ---- 4 k-steps x 4 column tiles of v_mfma_f32_16x16x4_f32 ----------------------------
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        const float a = As[(wave * 16 + fr) * LDAS + ks * 4 + fq];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float b = Bs[(ks * 4 + fq) * LDBS + t * 16 + fr];
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-        }
-      }
-      __syncthreads();
+      cur ^= 1;
     }
 
-    // ---- epilogue: lane holds rows r0 + wave*16 + fq*4 + j (j = 0..3), column c0 + t*16 + fr --
+    // ---- epilogue: lane holds rows r0 + rt*16 + fq*4 + j (j = 0..3), column c0 + (ct0+t)*16 + fr ---
+    // Row-major outputs (NONE, BN_TANH) are staged through the (now idle) slab buffers so that every lane
+    // stores 16 contiguous bytes of one output row: a dword-per-lane store of the accumulator layout touches
+    // 64-byte pieces of four rows per instruction and made the store tail the longest phase of the kernel.
+    constexpr bool STAGED = FAST && (EPI == EPI_NONE || EPI == EPI_BN_TANH);
+    float *os = Bs;  // [BM][LDB]; 2*KS*LDB == BM*LDB floats
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = c0 + t * 16 + fr;
-      if (col >= p.ncols) continue;
+    for (int t = 0; t < NTW; ++t) {
+      const int lcol = (ct0 + t) * 16 + fr;
+      const int col = c0 + lcol;
+      if (t >= nct || col >= p.ncols) continue;
       float cb = 0.f, mean = 0.f, inv = 1.f, gam = 1.f, bet = 0.f, tgt = 0.f;
       int64_t ob = -1;
       if (EPI == EPI_BN_TANH) {
@@ -172,16 +222,17 @@ __global__ __launch_bounds__(256) void tile_kernel(TileArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t row = r0 + wave * 16 + fq * 4 + j;
+        const int lrow = rt * 16 + fq * 4 + j;
+        const int64_t row = r0 + lrow;
         if (row >= p.m) continue;
         const float v = acc[t][j];
         if (EPI == EPI_NONE) {
-          p.c[row * p.ldc + col] = v;
+          if (STAGED) os[lrow * LDB + lcol] = v; else p.c[row * p.ldc + col] = v;
         } else if (EPI == EPI_BN_TANH) {
           float o = v / 3.0f;
           if (p.bias) o = o + cb;
-          o = (o - mean) * inv * gam + bet;
-          p.c[row * p.ldc + col] = tanhf(o);
+          o = tanhf_((o - mean) * inv * gam + bet);
+          if (STAGED) os[lrow * LDB + lcol] = o; else p.c[row * p.ldc + col] = o;
         } else if (EPI == EPI_SIGMOID) {
           p.c[int64_t(col) * p.ldc + row] = sigmoidf_(v + p.bias[row]);
         } else if (EPI == EPI_TARGET) {
@@ -201,33 +252,83 @@ __global__ __launch_bounds__(256) void tile_kernel(TileArgs p) {
         }
       }
     }
+    if (STAGED) {
+      __syncthreads();
+      const int c4n = (((p.ncols - c0) < BNC ? (p.ncols - c0) : BNC) + 3) / 4;  // float4 pieces per row (ncols % 4 == 0)
+      const bool vec_out = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.c) & 15u) == 0);
+      for (int s4 = tid; s4 < BM * c4n; s4 += THREADS) {
+        const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
+        const int64_t row = r0 + lrow;
+        if (row >= p.m) continue;
+        const float4 v4 = *reinterpret_cast<const float4 *>(os + lrow * LDB + lc);
+        float *dst = p.c + row * p.ldc + c0 + lc;
+        if (vec_out) {
+          *reinterpret_cast<float4 *>(dst) = v4;
+        } else {
+          dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+        }
+      }
+    }
   }
 
   if (EPI == EPI_RANK) {
     // lanes fr, fr+16, fr+32, fr+48 hold the same query column: fold, then one LDS add per wave
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTW; ++t) {
       unsigned int g = my_gt[t], l = my_tl[t], e = my_ti[t];
       g += __shfl_xor(g, 16); l += __shfl_xor(l, 16); e += __shfl_xor(e, 16);
       g += __shfl_xor(g, 32); l += __shfl_xor(l, 32); e += __shfl_xor(e, 32);
-      if (fq == 0) {
-        atomicAdd(&cnt[(t * 16 + fr) * 3 + 0], g);
-        atomicAdd(&cnt[(t * 16 + fr) * 3 + 1], l);
-        atomicAdd(&cnt[(t * 16 + fr) * 3 + 2], e);
+      if (fq == 0 && t < nct) {
+        atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 0], g);
+        atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 1], l);
+        atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 2], e);
       }
     }
     __syncthreads();
-    for (int i = tid; i < BN * 3; i += 256) {
+    for (int i = tid; i < BNC * 3; i += THREADS) {
       const int col = c0 + i / 3;
       if (col < p.ncols && cnt[i]) atomicAdd(&p.counts[int64_t(col) * 3 + i % 3], (unsigned long long)cnt[i]);
     }
   }
 }
 
+// all_rel = rels_embs @ rels_weight (model.py:107 without the dropped last row): [T, K] x [K, O], T tiny, so
+// the kernel is pure latency. Block = (one output row, 64 columns); its 4 waves split K and keep UNR
+// independent loads in flight per lane; partial sums meet in LDS and are added in wave order.
+__global__ __launch_bounds__(256) void small_matmul_kernel(const float *__restrict__ a, int64_t lda,
+                                                           const float *__restrict__ b, int64_t ldb,
+                                                           float *__restrict__ c, int64_t ldc, int k, int n) {
+  constexpr int UNR = 8;
+  __shared__ float part[4][64];
+  const int row = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  const int kper = (k + 3) / 4, k0 = wave * kper, k1 = (k0 + kper < k) ? k0 + kper : k;
+  const bool ok = col < n;
+  const float *ap = a + int64_t(row) * lda;
+  const float *bp = b + (ok ? col : 0);
+  float acc = 0.f;
+  int kk = k0;
+  for (; kk + UNR <= k1; kk += UNR) {
+    float av[UNR], bv[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      av[u] = ap[kk + u];
+      bv[u] = bp[int64_t(kk + u) * ldb];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc = fmaf(av[u], bv[u], acc);
+  }
+  for (; kk < k1; ++kk) acc = fmaf(ap[kk], bp[int64_t(kk) * ldb], acc);
+  part[wave][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (wave == 0 && ok) {
+    const int l = threadIdx.x;
+    c[int64_t(row) * ldc + col] = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+  }
+}
+
 void set_vec_flags(TileArgs *p) {
   p->a_vec = (p->lda % 4 == 0) && mgcn::aligned16(p->a);
-  p->b_vec = (p->ldb % 4 == 0) && mgcn::aligned16(p->b[0]) && (!p->b[1] || mgcn::aligned16(p->b[1])) &&
-             (!p->b[2] || mgcn::aligned16(p->b[2]));
+  p->b_vec = (p->ldb % 4 == 0) && mgcn::aligned16(p->b);
 }
 
 int check_common(const char *who, int64_t m, int32_t k, int64_t ncols) {
@@ -236,31 +337,56 @@ int check_common(const char *who, int64_t m, int32_t k, int64_t ncols) {
   return MGCN_OK;
 }
 
+// column tiles per wave: the smallest instantiated NT that covers the columns in one block, else 8/16-wide strips
+int pick_nt(int64_t ncols) {
+  if (ncols <= 32) return 2;
+  if (ncols <= 64) return 4;
+  if (ncols <= 128) return 8;
+  if (ncols <= 208) return 13;
+  return (ncols % 208 == 0 || ncols > 1024) ? 13 : 8;
+}
+
+template <int EPI, bool B_NT>
+int launch(TileArgs &p, int64_t grid_x_cap, hipStream_t stream, const char *name) {
+  set_vec_flags(&p);
+  p.tiles_m = int32_t((p.m + BM - 1) / BM);
+  const bool fast = p.a_vec && p.b_vec && p.k % 4 == 0 && (B_NT || p.ncols % 4 == 0);
+  const int nt = fast ? pick_nt(p.ncols) : 4;
+  const unsigned gy = unsigned((p.ncols + nt * 16 - 1) / (nt * 16));
+  const unsigned gx = unsigned(grid_x_cap > 0 && p.tiles_m > grid_x_cap ? grid_x_cap : p.tiles_m);
+  if (!fast) {
+    hipLaunchKernelGGL((tile_kernel<EPI, B_NT, 4, false>), dim3(gx, gy), dim3(THREADS), 0, stream, p);
+  } else {
+    switch (nt) {
+      case 2: hipLaunchKernelGGL((tile_kernel<EPI, B_NT, 2, true>), dim3(gx, gy), dim3(THREADS), 0, stream, p); break;
+      case 4: hipLaunchKernelGGL((tile_kernel<EPI, B_NT, 4, true>), dim3(gx, gy), dim3(THREADS), 0, stream, p); break;
+      case 8: hipLaunchKernelGGL((tile_kernel<EPI, B_NT, 8, true>), dim3(gx, gy), dim3(THREADS), 0, stream, p); break;
+      default: hipLaunchKernelGGL((tile_kernel<EPI, B_NT, 13, true>), dim3(gx, gy), dim3(THREADS), 0, stream, p); break;
+    }
+  }
+  MGCN_CHECK_LAUNCH(name);
+  return MGCN_OK;
+}
+
 }  // namespace
 
 extern "C" int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, const float *a_dev,
-                                      int64_t lda, const float *w_in_dev, const float *w_out_dev,
-                                      const float *w_loop_dev, const float *bias_dev, const float *bn_mean_dev,
+                                      int64_t lda, const float *w_dev, const float *bias_dev, const float *bn_mean_dev,
                                       const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
                                       float bn_eps, float *out_dev, int64_t ldo, void *stream) {
   if (int rc = check_common("dense_bn_tanh_fwd", num_nodes, dim_in, dim_out)) return rc;
-  MGCN_REQUIRE(a_dev && w_in_dev && w_out_dev && w_loop_dev && bn_mean_dev && bn_var_dev && bn_gamma_dev &&
-                   bn_beta_dev && out_dev, "dense_bn_tanh_fwd: null pointer");
+  MGCN_REQUIRE(a_dev && w_dev && bn_mean_dev && bn_var_dev && bn_gamma_dev && bn_beta_dev && out_dev,
+               "dense_bn_tanh_fwd: null pointer");
   MGCN_REQUIRE(lda >= 3 * int64_t(dim_in) && ldo >= dim_out, "dense_bn_tanh_fwd: lda/ldo too small");
   if (num_nodes == 0 || dim_out == 0) return MGCN_OK;
   TileArgs p = {};
   p.a = a_dev; p.lda = lda;
-  p.b[0] = w_in_dev; p.b[1] = w_out_dev; p.b[2] = w_loop_dev; p.ldb = dim_out; p.ksplit = dim_in;
+  p.b = w_dev; p.ldb = dim_out;
   p.c = out_dev; p.ldc = ldo;
   p.bias = bias_dev; p.bn_mean = bn_mean_dev; p.bn_var = bn_var_dev; p.bn_gamma = bn_gamma_dev; p.bn_beta = bn_beta_dev;
   p.bn_eps = bn_eps;
   p.m = num_nodes; p.k = 3 * dim_in; p.ncols = dim_out;
-  p.tiles_m = int32_t((num_nodes + BM - 1) / BM); p.tiles_n = (dim_out + BN - 1) / BN;
-  set_vec_flags(&p);
-  hipLaunchKernelGGL((tile_kernel<EPI_BN_TANH, false>), dim3(unsigned(p.tiles_m) * unsigned(p.tiles_n)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
-  MGCN_CHECK_LAUNCH("tile_kernel<BN_TANH>");
-  return MGCN_OK;
+  return launch<EPI_BN_TANH, false>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<BN_TANH>");
 }
 
 extern "C" int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t lda, const float *b_dev,
@@ -269,17 +395,18 @@ extern "C" int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_d
   MGCN_REQUIRE(a_dev && b_dev && c_dev, "matmul_f32: null pointer");
   MGCN_REQUIRE(lda >= k && ldb >= n && ldc >= n, "matmul_f32: leading dimension too small");
   if (m == 0 || n == 0) return MGCN_OK;
+  if (m <= 1024 && n <= 4096) {  // relation projection: a few dozen rows, latency bound
+    hipLaunchKernelGGL(small_matmul_kernel, dim3(unsigned(m), unsigned((n + 63) / 64)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a_dev, lda, b_dev, ldb, c_dev, ldc, k, n);
+    MGCN_CHECK_LAUNCH("small_matmul_kernel");
+    return MGCN_OK;
+  }
   TileArgs p = {};
   p.a = a_dev; p.lda = lda;
-  p.b[0] = b_dev; p.ldb = ldb; p.ksplit = k;
+  p.b = b_dev; p.ldb = ldb;
   p.c = c_dev; p.ldc = ldc;
   p.m = m; p.k = k; p.ncols = n;
-  p.tiles_m = int32_t((m + BM - 1) / BM); p.tiles_n = (n + BN - 1) / BN;
-  set_vec_flags(&p);
-  hipLaunchKernelGGL((tile_kernel<EPI_NONE, false>), dim3(unsigned(p.tiles_m) * unsigned(p.tiles_n)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
-  MGCN_CHECK_LAUNCH("tile_kernel<NONE>");
-  return MGCN_OK;
+  return launch<EPI_NONE, false>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<NONE>");
 }
 
 extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx,
@@ -291,16 +418,11 @@ extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const
   if (batch == 0 || n_local == 0) return MGCN_OK;
   TileArgs p = {};
   p.a = ent_dev; p.lda = lde;
-  p.b[0] = x_dev; p.ldb = ldx;
+  p.b = x_dev; p.ldb = ldx;
   p.c = score_dev; p.ldc = lds;
   p.bias = bias_dev;
   p.m = n_local; p.k = dim; p.ncols = batch;
-  p.tiles_m = int32_t((n_local + BM - 1) / BM); p.tiles_n = (batch + BN - 1) / BN;
-  set_vec_flags(&p);
-  hipLaunchKernelGGL((tile_kernel<EPI_SIGMOID, true>), dim3(unsigned(p.tiles_m) * unsigned(p.tiles_n)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
-  MGCN_CHECK_LAUNCH("tile_kernel<SIGMOID>");
-  return MGCN_OK;
+  return launch<EPI_SIGMOID, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<SIGMOID>");
 }
 
 extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
@@ -312,16 +434,11 @@ extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row
   if (batch == 0 || n_local == 0) return MGCN_OK;
   TileArgs p = {};
   p.a = ent_dev; p.lda = lde;
-  p.b[0] = x_dev; p.ldb = ldx;
+  p.b = x_dev; p.ldb = ldx;
   p.n_local = n_local;
   p.bias = bias_dev; p.obj = obj_dev; p.target_out = target_dev; p.row0 = ent_row0;
   p.m = batch; p.k = dim; p.ncols = batch;
-  p.tiles_m = (batch + BM - 1) / BM; p.tiles_n = (batch + BN - 1) / BN;
-  set_vec_flags(&p);
-  hipLaunchKernelGGL((tile_kernel<EPI_TARGET, true>), dim3(unsigned(p.tiles_m) * unsigned(p.tiles_n)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
-  MGCN_CHECK_LAUNCH("tile_kernel<TARGET>");
-  return MGCN_OK;
+  return launch<EPI_TARGET, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<TARGET>");
 }
 
 extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
@@ -335,15 +452,9 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
   if (batch == 0 || n_local == 0) return MGCN_OK;
   TileArgs p = {};
   p.a = ent_dev; p.lda = lde;
-  p.b[0] = x_dev; p.ldb = ldx;
+  p.b = x_dev; p.ldb = ldx;
   p.bias = bias_dev; p.obj = obj_dev; p.target = target_dev; p.label = label_dev; p.ldl = ldl;
   p.counts = reinterpret_cast<unsigned long long *>(counts_dev); p.row0 = ent_row0;
   p.m = n_local; p.k = dim; p.ncols = batch;
-  p.tiles_m = int32_t((n_local + BM - 1) / BM); p.tiles_n = (batch + BN - 1) / BN;
-  const unsigned gx = unsigned(p.tiles_m < 512 ? p.tiles_m : 512);
-  set_vec_flags(&p);
-  hipLaunchKernelGGL((tile_kernel<EPI_RANK, true>), dim3(gx, unsigned(p.tiles_n)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p);
-  MGCN_CHECK_LAUNCH("tile_kernel<RANK>");
-  return MGCN_OK;
+  return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
 }
