@@ -141,7 +141,9 @@ int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t
  *   gt   = #{n != obj[b], not filtered : score[b,n] >  target[b]}
  *   tl   = #{n != obj[b], not filtered, n <  obj[b] : score[b,n] == target[b]}   (ties_lower)
  *   ties = #{n != obj[b], not filtered : score[b,n] == target[b]}
- * where n is filtered iff label[b, n] (f32, row stride ldl, the shard's own columns) is >= 1.
+ * where n is filtered iff label[b, n] != 0 after the reference's label.byte() (f32 rows, stride ldl, the shard's own
+ * columns), or — when mask_dev is given instead of label_dev — iff bit (n & 31) of mask[b, n >> 5] is set
+ * (uint32 rows, stride ldm words; built on the device by mgcn_filter_mask). Exactly one of label_dev / mask_dev.
  * counts [B,3] int64 must be zeroed by the caller; integer atomics => order independent.
  * rank = 1 + gt (+ tl under the stable tie rule). With an entity shard per GPU the caller sums
  * counts over ranks (RCCL all-reduce); `ent_row0` is the shard's first global entity id.
@@ -155,7 +157,15 @@ int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t 
 int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
                     int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                    int64_t *counts_dev, void *stream);
+                    const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
+
+/* Filter bits on the device (replaces building + shipping the dense [B, N] label block of data_loader.py:34-51
+ * for evaluation). keys_dev [num_keys] sorted int64 (subject * num_rel_ids + relation), ptr_dev
+ * [num_keys+1], tails_dev [ptr[num_keys]] int32: the known tails of each (subject, relation). For query b with key
+ * qkey_dev[b] the bits of its tails inside [ent_row0, ent_row0 + n_local) are set in mask_dev[b, :] (zeroed here). */
+int mgcn_filter_mask(int32_t batch, const int64_t *qkey_dev, int64_t num_keys, const int64_t *keys_dev,
+                     const int64_t *ptr_dev, const int32_t *tails_dev, int64_t ent_row0, int64_t n_local,
+                     uint32_t *mask_dev, int64_t ldm, void *stream);
 
 #ifdef __cplusplus
 }

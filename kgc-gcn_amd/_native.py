@@ -31,7 +31,8 @@ _SIGNATURES = {
     'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
-                                       _ptr, _ptr]),
+                                       _ptr, _i64, _ptr, _ptr]),
+    'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))
@@ -237,16 +238,42 @@ def score_target(x, ent, bias, obj, ent_row0=0, out=None):
     return out
 
 
-def score_rank(x, ent, bias, obj, target, label, ent_row0=0, counts=None):
-    """counts [B, 3] int64 += (gt, ties_lower, ties) over this shard's entities."""
+def score_rank(x, ent, bias, obj, target, label=None, ent_row0=0, counts=None, mask=None):
+    """counts [B, 3] int64 += (gt, ties_lower, ties) over this shard's entities. Filter = dense `label` rows [B, n]
+    (reference loader) or the bit-packed `mask` [B, ceil(n/32)] int32 from filter_mask()."""
     B, n, O = _score_args(x, ent, bias)
-    if obj.numel() != B or target.numel() != B or label.dim() != 2 or label.size(0) != B or label.size(1) != n:
-        raise NativeError('score_rank: obj/target/label do not match batch %d x shard %d' % (B, n))
+    if (label is None) == (mask is None):
+        raise NativeError('score_rank: give exactly one of label / mask')
+    if obj.numel() != B or target.numel() != B:
+        raise NativeError('score_rank: obj/target do not match batch %d' % B)
+    if label is not None and (label.dim() != 2 or label.size(0) != B or label.size(1) != n):
+        raise NativeError('score_rank: label must be (%d, %d)' % (B, n))
+    if mask is not None and (mask.dim() != 2 or mask.size(0) != B or mask.size(1) < (n + 31) // 32 or not mask.is_contiguous()):
+        raise NativeError('score_rank: mask must be contiguous (%d, >= %d)' % (B, (n + 31) // 32))
     if counts is None:
         counts = torch.zeros((B, 3), dtype=torch.int64, device=x.device)
+    _same_device(x, ent, bias, obj, target, label, mask, counts)
     _check(lib().mgcn_score_rank(B, n, int(ent_row0), O, _dev(x, torch.float32, 'x'), _ld(x),
                                  _dev(ent, torch.float32, 'ent'), _ld(ent), _dev(bias, torch.float32, 'bias'),
                                  _dev(obj, torch.int64, 'obj'), _dev(target, torch.float32, 'target'),
-                                 _dev(label, torch.float32, 'label'), _ld(label), _dev(counts, torch.int64, 'counts'),
-                                 _stream(x)), 'mgcn_score_rank')
+                                 _dev(label, torch.float32, 'label', True), _ld(label) if label is not None else 0,
+                                 _dev(mask, torch.int32, 'mask', True), mask.size(1) if mask is not None else 0,
+                                 _dev(counts, torch.int64, 'counts'), _stream(x)), 'mgcn_score_rank')
     return counts
+
+
+def filter_mask(qkey, keys, ptr, tails, n_local, ent_row0=0, out=None):
+    """Bit-packed filter rows [B, ceil(n_local/32)] int32 for queries with keys `qkey` (see mgcn_filter_mask)."""
+    B, words = qkey.numel(), (int(n_local) + 31) // 32
+    if out is None:
+        out = torch.empty((B, words), dtype=torch.int32, device=qkey.device)
+    if out.size(0) != B or out.size(1) < words or not out.is_contiguous():
+        raise NativeError('filter_mask: out must be contiguous (%d, >= %d)' % (B, words))
+    if ptr.numel() != keys.numel() + 1:
+        raise NativeError('filter_mask: ptr must have len(keys) + 1 entries')
+    _same_device(qkey, keys, ptr, tails, out)
+    _check(lib().mgcn_filter_mask(B, _dev(qkey, torch.int64, 'qkey'), keys.numel(), _dev(keys, torch.int64, 'keys'),
+                                  _dev(ptr, torch.int64, 'ptr'), _dev(tails, torch.int32, 'tails'), int(ent_row0),
+                                  int(n_local), _dev(out, torch.int32, 'mask'), out.size(1), _stream(qkey)),
+           'mgcn_filter_mask')
+    return out

@@ -37,7 +37,8 @@ struct TileArgs {
   const int64_t *obj;    // scoring: [ncols] target entity (global id) per query
   const float *target;   // RANK: [ncols]
   float *target_out;     // TARGET: [ncols]
-  const float *label;    // RANK: [ncols, ldl]
+  const float *label;    // RANK: [ncols, ldl] dense 0/1 rows, or
+  const uint32_t *mask;  // RANK: [ncols, ldl] words, bit (n & 31) of word n >> 5 set = entity n filtered
   unsigned long long *counts;  // RANK: [ncols, 3]
   int64_t lda, ldb, ldc, ldl, m, row0, n_local;
   int32_t k, ncols, tiles_m;
@@ -74,7 +75,11 @@ __device__ __forceinline__ float4 load4(const float *ptr, bool ok, int first, in
 }
 
 template <bool B_NT, int NT, bool FAST>
-struct BStage {
+struct BStage;
+
+// Generic shapes: element-wise guarded loads with zero fill.
+template <bool B_NT, int NT>
+struct BStage<B_NT, NT, false> {
   static constexpr int BNC = NT * 16;
   static constexpr int LDB = BNC + 4;
   // NN: slots of 4 consecutive columns of one k-row; NT: slots of 4 consecutive k of one column
@@ -82,17 +87,19 @@ struct BStage {
   static constexpr int PER_THREAD = (SLOTS + THREADS - 1) / THREADS;
   float4 v[PER_THREAD];
 
+  __device__ __forceinline__ void init(const TileArgs &, int, int) {}
+
   __device__ __forceinline__ void load(const TileArgs &p, int kb, int c0, int tid) {
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j) {
       const int s = tid + j * THREADS;
       if (B_NT) {
         const int c = s >> 2, kk = kb * KS + (s & 3) * 4;
-        v[j] = load4<FAST>(p.b + int64_t(c0 + c) * p.ldb + kk, s < SLOTS && c0 + c < p.ncols, kk, p.k);
+        v[j] = load4<false>(p.b + int64_t(c0 + c) * p.ldb + kk, s < SLOTS && c0 + c < p.ncols, kk, p.k);
       } else {
         const int r = s / (BNC / 4), cc = c0 + (s % (BNC / 4)) * 4;
         const int kk = kb * KS + r;
-        v[j] = load4<FAST>(p.b + int64_t(kk) * p.ldb + cc, s < SLOTS && kk < p.k, cc, p.ncols);
+        v[j] = load4<false>(p.b + int64_t(kk) * p.ldb + cc, s < SLOTS && kk < p.k, cc, p.ncols);
       }
     }
   }
@@ -117,14 +124,131 @@ struct BStage {
   }
 };
 
+// Aligned shapes (16-byte aligned operands, K and the column count multiples of 4): every slot is ONE
+// unconditional dwordx4 whose address is loop-invariant except for the k-block advance. Nothing is
+// zero-filled: a k-row past K is clamped to the last valid row and meets an A fragment that IS zero-filled,
+// and a column past ncols is clamped to a valid column whose results the epilogue never stores. Slots past
+// the slab (last j of some threads) repeat the last slot (same bytes to the same LDS address).
+template <bool B_NT, int NT>
+struct BStage<B_NT, NT, true> {
+  static constexpr int BNC = NT * 16;
+  static constexpr int LDB = BNC + 4;
+  static constexpr int SLOTS = B_NT ? BNC * 4 : KS * (BNC / 4);
+  static constexpr int PER_THREAD = (SLOTS + THREADS - 1) / THREADS;
+  float4 v[PER_THREAD];
+  int goff[PER_THREAD];   // NN: column (elements); NT: row offset c*ldb (elements)
+  int krow[PER_THREAD];   // NN: k-row inside the slab; NT: first k of the quad inside the slab
+  int loff[PER_THREAD];   // LDS element offset of the slot
+
+  __device__ __forceinline__ void init(const TileArgs &p, int c0, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      int s = tid + j * THREADS;
+      s = s < SLOTS ? s : SLOTS - 1;
+      if (B_NT) {
+        const int c = s >> 2;
+        int cg = c0 + c;
+        cg = cg < p.ncols ? cg : p.ncols - 1;
+        goff[j] = cg * int(p.ldb);
+        krow[j] = (s & 3) * 4;
+        loff[j] = krow[j] * LDB + c;
+      } else {
+        const int r = s / (BNC / 4), cq = (s % (BNC / 4)) * 4;
+        int cc = c0 + cq;
+        cc = cc < p.ncols ? cc : p.ncols - 4;
+        goff[j] = cc;
+        krow[j] = r;
+        loff[j] = r * LDB + cq;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const TileArgs &p, int kb, int, int) {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      int kk = kb * KS + krow[j];
+      if (B_NT) {
+        kk = kk < p.k ? kk : p.k - 4;
+        v[j] = *reinterpret_cast<const float4 *>(p.b + goff[j] + kk);
+      } else {
+        kk = kk < p.k ? kk : p.k - 1;
+        v[j] = *reinterpret_cast<const float4 *>(p.b + int64_t(kk) * p.ldb + goff[j]);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float *bs, int) const {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      if (B_NT) {
+        bs[loff[j] + 0 * LDB] = v[j].x;
+        bs[loff[j] + 1 * LDB] = v[j].y;
+        bs[loff[j] + 2 * LDB] = v[j].z;
+        bs[loff[j] + 3 * LDB] = v[j].w;
+      } else {
+        *reinterpret_cast<float4 *>(bs + loff[j]) = v[j];
+      }
+    }
+  }
+};
+
+// NN + aligned shapes: the weight slab goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), 1 KiB per
+// wave-instruction, no staging registers and no ds_write pass. The LDS image is the same [KS][LDB] slab;
+// a lane's 16 bytes land at piece*1024 + lane*16, so its SOURCE address is computed from that offset
+// (row = offset / row bytes, column = remainder); bytes that fall in a row's 16-byte pad or past the slab
+// read some valid address and are never used. Clamping rules as in BStage<.., true>.
+template <int NT>
+struct BDma {
+  static constexpr int BNC = NT * 16;
+  static constexpr int LDB = BNC + 4;
+  static constexpr int ROW_BYTES = LDB * 4;
+  static constexpr int PIECES = (KS * ROW_BYTES + 1023) / 1024;
+  static constexpr int SLAB_F = PIECES * 256;            // floats per buffer (whole pieces)
+  static constexpr int PPW = (PIECES + WAVES - 1) / WAVES;  // pieces per wave
+  int rr[PPW], cc[PPW];
+
+  __device__ __forceinline__ void init(const TileArgs &p, int c0, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int o = (wave + j * WAVES) * 1024 + lane * 16;
+      int r = o / ROW_BYTES, c = (o - r * ROW_BYTES) >> 2;
+      r = r < KS ? r : KS - 1;
+      c = c < BNC ? c : BNC - 4;
+      int cg = c0 + c;
+      cg = cg < p.ncols ? cg : p.ncols - 4;
+      rr[j] = r;
+      cc[j] = cg;
+    }
+  }
+
+  __device__ __forceinline__ void issue(const TileArgs &p, int kb, float *slab, int wave) const {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int piece = wave + j * WAVES;  // wave-uniform
+      if (piece < PIECES) {
+        int kk = kb * KS + rr[j];
+        kk = kk < p.k ? kk : p.k - 1;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(p.b + int64_t(kk) * p.ldb + cc[j]),
+            (__attribute__((address_space(3))) void *)(slab + piece * 256), 16, 0, 0);
+      }
+    }
+  }
+};
+
 template <int EPI, bool B_NT, int NT, bool FAST>
 __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
   using Stage = BStage<B_NT, NT, FAST>;
+  using Dma = BDma<NT>;
+  constexpr bool DMA = FAST && !B_NT;
   constexpr int BNC = Stage::BNC, LDB = Stage::LDB;
   constexpr int NTW = (NT + 1) / 2;  // column tiles of a wave in the first half; the second half has NT - NTW
-  __shared__ __attribute__((aligned(16))) float Bs[2 * KS * LDB];
+  constexpr int SLAB_F = DMA ? Dma::SLAB_F : KS * LDB;
+  // ONE shared array (slabs, output staging, RANK counters): a second __shared__ object next to an LDS-DMA
+  // target makes hipcc drain vmcnt before every ds_read (cdna_hip_programming.md, M = 256 GEMM item 4a).
+  __shared__ __attribute__((aligned(16))) float Bs[2 * SLAB_F + (EPI == EPI_RANK ? BNC * 3 : 0)];
   static_assert(2 * KS == BM, "the output staging tile [BM][LDB] reuses the two slab buffers");
-  __shared__ unsigned int cnt[EPI == EPI_RANK ? BNC * 3 : 1];
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(Bs + 2 * SLAB_F);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -153,6 +277,10 @@ __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
 
     int64_t arow = r0 + rt * 16 + fr;
     bool a_ok = arow < p.m;
+    if (FAST && EPI != EPI_TARGET && !a_ok) {  // rows past M are never stored: read a valid row instead of predicating
+      arow = p.m - 1;
+      a_ok = true;
+    }
     if (EPI == EPI_TARGET && a_ok) {
       const int64_t o = p.obj[arow] - p.row0;  // the entity row query `arow` must be scored against
       a_ok = o >= 0 && o < p.n_local;
@@ -161,20 +289,31 @@ __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
     const float *aptr = p.a + (a_ok ? arow : 0) * p.lda;
 
     Stage st;
-    st.load(p, 0, c0, tid);
-    float4 a_cur = load4<FAST>(aptr + 4 * fq, a_ok, 4 * fq, p.k);
+    Dma dma;
     __syncthreads();  // previous tile's readers are done with buffer 0
-    st.store(Bs, tid);
+    if (DMA) {
+      dma.init(p, c0, wave, lane);
+      dma.issue(p, 0, Bs, wave);
+    } else {
+      st.init(p, c0, tid);
+      st.load(p, 0, c0, tid);
+    }
+    float4 a_cur = load4<FAST>(aptr + 4 * fq, a_ok, 4 * fq, p.k);
+    if (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      st.store(Bs, tid);
+    }
     __syncthreads();
     int cur = 0;
     for (int kb = 0; kb < nkb; ++kb) {
       float4 a_next = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool more = kb + 1 < nkb;
       if (more) {
-        st.load(p, kb + 1, c0, tid);
+        if (DMA) dma.issue(p, kb + 1, Bs + (cur ^ 1) * SLAB_F, wave); else st.load(p, kb + 1, c0, tid);
         a_next = load4<FAST>(aptr + (kb + 1) * KS + 4 * fq, a_ok, (kb + 1) * KS + 4 * fq, p.k);
       }
-      const float *bs = Bs + cur * KS * LDB + (4 * fq) * LDB + ct0 * 16 + fr;
+      const float *bs = Bs + cur * SLAB_F + (4 * fq) * LDB + ct0 * 16 + fr;
       const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
       // B fragments one MFMA step ahead: the ds_reads of step i+1 are in flight under step i's MFMAs
       float bf[2][NTW];
@@ -190,7 +329,11 @@ __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
         for (int t = 0; t < NTW; ++t)
           if (t < nct) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bf[i & 1][t], acc[t], 0, 0, 0);
       }
-      if (more) st.store(Bs + (cur ^ 1) * KS * LDB, tid);
+      if (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slab for kb+1 has landed (read it after the barrier)
+      } else if (more) {
+        st.store(Bs + (cur ^ 1) * SLAB_F, tid);
+      }
       a_cur = a_next;
       __syncthreads();
       cur ^= 1;
@@ -242,8 +385,12 @@ __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
           }
         } else if (EPI == EPI_RANK) {
           if (row == ob) continue;                                       // the target itself (main.py:125)
-          const float lab = p.label[int64_t(col) * p.ldl + row];
-          if ((static_cast<int>(lab) & 0xff) != 0) continue;              // label.byte() filter (main.py:124)
+          if (p.mask) {                                                    // bit-packed filter (uniform branch)
+            if ((p.mask[int64_t(col) * p.ldl + (row >> 5)] >> (row & 31)) & 1u) continue;
+          } else {
+            const float lab = p.label[int64_t(col) * p.ldl + row];
+            if ((static_cast<int>(lab) & 0xff) != 0) continue;            // label.byte() filter (main.py:124)
+          }
           const float s = sigmoidf_(v + p.bias[row]);
           my_gt[t] += s > tgt;
           const bool eq = s == tgt;
@@ -323,6 +470,28 @@ __global__ __launch_bounds__(256) void small_matmul_kernel(const float *__restri
   if (wave == 0 && ok) {
     const int l = threadIdx.x;
     c[int64_t(row) * ldc + col] = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+  }
+}
+
+// Filter construction on the device (replaces the dense [B, N] label block of data_loader.py:34-51 for
+// evaluation): known (subject, relation) -> tails lists live on the device as a sorted key array + CSR; one wave
+// per query finds its key by binary search and sets the bits of the tails that fall into this entity shard.
+__global__ __launch_bounds__(256) void filter_mask_kernel(const int64_t *__restrict__ qkey, int batch,
+                                                          const int64_t *__restrict__ keys, int64_t nkeys,
+                                                          const int64_t *__restrict__ ptr, const int32_t *__restrict__ tails,
+                                                          int64_t row0, int64_t n_local, uint32_t *mask, int64_t ldm) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= batch) return;
+  const int64_t key = qkey[q];
+  int64_t lo = 0, hi = nkeys;
+  while (lo < hi) {  // wave-uniform
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= nkeys || keys[lo] != key) return;
+  for (int64_t i = ptr[lo] + lane; i < ptr[lo + 1]; i += 64) {
+    const int64_t n = int64_t(tails[i]) - row0;
+    if (n >= 0 && n < n_local) atomicOr(&mask[int64_t(q) * ldm + (n >> 5)], 1u << (n & 31));
   }
 }
 
@@ -409,6 +578,21 @@ extern "C" int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_d
   return launch<EPI_NONE, false>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<NONE>");
 }
 
+extern "C" int mgcn_filter_mask(int32_t batch, const int64_t *qkey_dev, int64_t num_keys, const int64_t *keys_dev,
+                                const int64_t *ptr_dev, const int32_t *tails_dev, int64_t ent_row0, int64_t n_local,
+                                uint32_t *mask_dev, int64_t ldm, void *stream) {
+  MGCN_REQUIRE(batch >= 0 && num_keys >= 0 && n_local >= 0 && ent_row0 >= 0, "filter_mask: bad sizes");
+  MGCN_REQUIRE(ldm >= (n_local + 31) / 32, "filter_mask: mask rows too short");
+  if (batch == 0 || n_local == 0) return MGCN_OK;
+  MGCN_REQUIRE(qkey_dev && mask_dev && ptr_dev && (num_keys == 0 || (keys_dev && tails_dev)), "filter_mask: null pointer");
+  hipError_t e = hipMemsetAsync(mask_dev, 0, size_t(batch) * size_t(ldm) * sizeof(uint32_t), static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return mgcn::fail(MGCN_ELAUNCH, "filter_mask: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(filter_mask_kernel, dim3(unsigned((batch + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     qkey_dev, batch, keys_dev, num_keys, ptr_dev, tails_dev, ent_row0, n_local, mask_dev, ldm);
+  MGCN_CHECK_LAUNCH("filter_mask_kernel");
+  return MGCN_OK;
+}
+
 extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx,
                               const float *ent_dev, int64_t lde, const float *bias_dev, float *score_dev,
                               int64_t lds, void *stream) {
@@ -444,16 +628,18 @@ extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row
 extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
                                int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
                                const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                               int64_t *counts_dev, void *stream) {
+                               const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
   if (int rc = check_common("score_rank", n_local, dim, batch)) return rc;
-  MGCN_REQUIRE(x_dev && ent_dev && bias_dev && obj_dev && target_dev && label_dev && counts_dev,
-               "score_rank: null pointer");
-  MGCN_REQUIRE(ldx >= dim && lde >= dim && ldl >= n_local && ent_row0 >= 0, "score_rank: bad leading dimension / row0");
+  MGCN_REQUIRE(x_dev && ent_dev && bias_dev && obj_dev && target_dev && counts_dev, "score_rank: null pointer");
+  MGCN_REQUIRE((label_dev != nullptr) != (mask_dev != nullptr), "score_rank: give exactly one of label / mask");
+  MGCN_REQUIRE(ldx >= dim && lde >= dim && ent_row0 >= 0, "score_rank: bad leading dimension / row0");
+  MGCN_REQUIRE(label_dev ? ldl >= n_local : ldm >= (n_local + 31) / 32, "score_rank: filter rows too short");
   if (batch == 0 || n_local == 0) return MGCN_OK;
   TileArgs p = {};
   p.a = ent_dev; p.lda = lde;
   p.b = x_dev; p.ldb = ldx;
-  p.bias = bias_dev; p.obj = obj_dev; p.target = target_dev; p.label = label_dev; p.ldl = ldl;
+  p.bias = bias_dev; p.obj = obj_dev; p.target = target_dev; p.label = label_dev; p.mask = mask_dev;
+  p.ldl = label_dev ? ldl : ldm;
   p.counts = reinterpret_cast<unsigned long long *>(counts_dev); p.row0 = ent_row0;
   p.m = n_local; p.k = dim; p.ncols = batch;
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");

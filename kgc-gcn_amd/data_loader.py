@@ -77,6 +77,7 @@ class DataLoader(object):
             if split == 'train':
                 known_train = {k: list(v) for k, v in known.items()}
         known_all = {k: list(v) for k, v in known.items()}
+        self._known_all = known_all
         self.num_edge = len(ids['train'])
 
         self.triplets = {'train': [{'triple': (s, p, -1), 'label': objs, 'sub_samp': 1}
@@ -115,6 +116,17 @@ class DataLoader(object):
         graph.num_nodes = len(graph_nodes)
         graph.edge_norm = self._edge_normal(rel, edge_index, len(graph_nodes))
         return graph
+
+    def filter_index(self):
+        """Device-side form of the evaluation filter (every known tail of every (subject, relation), i.e. what the
+        dense label rows of the *_head / *_tail datasets mark): see dist.FilterIndex."""
+        from .dist import FilterIndex
+        return FilterIndex.from_known(self._known_all, 2 * self.num_relation)
+
+    def eval_queries(self, split):
+        """[Q, 3] int64 (subject, relation id, object): the split's tail queries followed by its head queries."""
+        rows = [q['triple'] for q in self.triplets[split + '_tail']] + [q['triple'] for q in self.triplets[split + '_head']]
+        return torch.tensor(rows, dtype=torch.int64).reshape(-1, 3)
 
     # -- query loaders ---------------------------------------------------------------------------
     def _get_dataset(self, data_type, params):

@@ -1,0 +1,120 @@
+"""Entity-sharded scoring and ranking across the GPUs of one node: one process per GPU,
+torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU rehearsal tests).
+
+Every rank keeps rows [row0, row0 + n_local) of the encoder output (its shard of the entity table), the matching
+slice of the decoder bias and a replica of the (small) filter index. Per step each rank brings its own block of B
+queries; the exchange is
+    all-gather   x [B, O], obj [B], key [B]          (query embeddings, 100 KB per rank: latency-bound)
+    all-reduce   target [W*B] f32  (sum; exactly one rank — the owner of obj — contributes a non-zero, so exact)
+    all-reduce   counts [W*B, 3] int64 (sum; integers, so sharded ranks are bit-identical to 1-GPU ranks)
+and the three local kernels (target, filter bits, score+filter+count) run on the shard. There is no collective
+in the aggregation itself when every rank holds the whole graph (FB15k-237: 12 MB of encoder output).
+"""
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+
+def shard_bounds(n, world):
+    """Contiguous, balanced row ranges: rank r owns [b[r], b[r+1])."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+class FilterIndex(object):
+    """Known (subject, relation) -> tails as a sorted key array + CSR (the loader's sr2o over train+valid+test,
+    data_loader.py:80-96), for building the evaluation filter on the device instead of dense [B, N] label rows."""
+
+    def __init__(self, keys, ptr, tails, num_rel_ids):
+        self.keys, self.ptr, self.tails, self.num_rel_ids = keys, ptr, tails, int(num_rel_ids)
+
+    @classmethod
+    def from_known(cls, known, num_rel_ids):
+        items = sorted(((s * num_rel_ids + r), sorted(ts)) for (s, r), ts in known.items())
+        keys = torch.tensor([k for k, _ in items], dtype=torch.int64)
+        lens = torch.tensor([len(t) for _, t in items], dtype=torch.int64)
+        ptr = torch.zeros(len(items) + 1, dtype=torch.int64)
+        ptr[1:] = torch.cumsum(lens, 0)
+        tails = torch.tensor([t for _, ts in items for t in ts], dtype=torch.int32)
+        return cls(keys, ptr, tails, num_rel_ids)
+
+    def to(self, device):
+        self.keys, self.ptr, self.tails = self.keys.to(device), self.ptr.to(device), self.tails.to(device)
+        return self
+
+    def query_keys(self, sub, rel):
+        return sub.to(torch.int64) * self.num_rel_ids + rel.to(torch.int64)
+
+
+def _gather(t, group, world):
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return torch.cat(out, dim=0)
+
+
+def sharded_rank_counts(x, qkey, obj, ent_shard, bias_shard, row0, filt, group=None, kernels=_native):
+    """Filtered-rank counts of this rank's B queries against the WHOLE entity table, which is sharded by rows.
+    x [B, O] query embeddings (ConvE trunk output), qkey [B] filter keys, obj [B] target entity (global id).
+    Returns (counts [B, 3] int64 = gt / ties_lower / ties, target [B] f32). All ranks must pass the same B."""
+    world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    B = x.size(0)
+    if world > 1:
+        x_all, key_all, obj_all = _gather(x, group, world), _gather(qkey, group, world), _gather(obj, group, world)
+    else:
+        x_all, key_all, obj_all = x.contiguous(), qkey, obj
+    n_local = ent_shard.size(0)
+    target = torch.zeros(x_all.size(0), dtype=torch.float32, device=x.device)
+    kernels.score_target(x_all, ent_shard, bias_shard, obj_all, ent_row0=row0, out=target)
+    if world > 1:
+        dist.all_reduce(target, op=dist.ReduceOp.SUM, group=group)
+    mask = kernels.filter_mask(key_all, filt.keys, filt.ptr, filt.tails, n_local, ent_row0=row0)
+    counts = kernels.score_rank(x_all, ent_shard, bias_shard, obj_all, target, mask=mask, ent_row0=row0)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    return counts[rank * B:(rank + 1) * B], target[rank * B:(rank + 1) * B]
+
+
+@torch.no_grad()
+def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None):
+    """Filtered MR / MRR / hits@{1,3,10} of `queries` ([Q, 3] int64: subject, relation id, object; both directions
+    already expanded, as the loader's *_tail + *_head lists) with the entity table sharded over the group.
+    Rank r scores batches r, r + W, ...; the tail is padded so every rank runs the same number of collectives."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    model.eval()
+    all_ent, all_rel = model.encode(graph)                     # replicated encoder; this rank keeps its row shard
+    N = all_ent.size(0)
+    b = shard_bounds(N, world)
+    ent_shard = all_ent[b[rank]:b[rank + 1]].contiguous()
+    bias_shard = model.conv2.bias[b[rank]:b[rank + 1]].contiguous()
+    dev = all_ent.device
+    Q = queries.size(0)
+    nb = (Q + batch_size - 1) // batch_size
+    rounds = (nb + world - 1) // world
+    sums = torch.zeros(5, dtype=torch.float64, device=dev)     # count, mr, mrr, hits@1, hits@3 ... filled below
+    hits = torch.zeros(10, dtype=torch.float64, device=dev)
+    for it in range(rounds):
+        bi = it * world + rank
+        lo, hi = min(bi * batch_size, Q), min((bi + 1) * batch_size, Q)
+        real = hi - lo
+        q = queries[lo:hi].to(dev)
+        if real < batch_size:                                   # pad with a harmless query; its result is dropped
+            pad = torch.zeros((batch_size - real, 3), dtype=torch.int64, device=dev)
+            q = torch.cat([q, pad], dim=0)
+        sub, rel, obj = q[:, 0], q[:, 1], q[:, 2].contiguous()
+        x = model.conv2.trunk(all_ent.index_select(0, sub), all_rel.index_select(0, rel))
+        counts, _ = sharded_rank_counts(x, filt.query_keys(sub, rel), obj, ent_shard, bias_shard, b[rank], filt, group)
+        ranks = (1 + counts[:real, 0] + counts[:real, 1]).double()
+        sums[0] += real
+        sums[1] += ranks.sum()
+        sums[2] += (1.0 / ranks).sum()
+        hits += (ranks.view(-1, 1) <= torch.arange(1, 11, device=dev, dtype=torch.float64)).sum(0)
+    if world > 1:
+        dist.all_reduce(sums, group=group)
+        dist.all_reduce(hits, group=group)
+    count = float(sums[0])
+    res = {'count': count, 'mr': float(sums[1]) / count, 'mrr': float(sums[2]) / count}
+    for k in (1, 3, 10):
+        res['hits@%d' % k] = float(hits[k - 1]) / count
+    return res

@@ -322,12 +322,19 @@ class MGCN(nn.Module):
 
     # -- fused evaluation path (main.py:121-126 without materialising [B, N] scores) -------------
     @torch.no_grad()
-    def rank_counts(self, src, rel, obj, label, data):
+    def rank_counts(self, src, rel, obj, label, data, filter_index=None):
         """Per query: gt / ties_lower / ties (int64 [B, 3]) and the target score [B]. Filtered rank under the
-        stable tie rule = 1 + gt + ties_lower; on rows with ties == 0 it equals the reference's rank exactly."""
+        stable tie rule = 1 + gt + ties_lower; on rows with ties == 0 it equals the reference's rank exactly.
+        The filter is the dense `label` block of the reference loader, or (label=None) a dist.FilterIndex from
+        which the bits are built on the device."""
         all_ent, all_rel = self.encode(data)
         x = self.conv2.trunk(torch.index_select(all_ent, 0, src), torch.index_select(all_rel, 0, rel))
         ent = all_ent.contiguous()
         target = _native.score_target(x, ent, self.conv2.bias, obj)
-        counts = _native.score_rank(x, ent, self.conv2.bias, obj, target, label.contiguous())
+        if label is not None:
+            counts = _native.score_rank(x, ent, self.conv2.bias, obj, target, label=label.contiguous())
+        else:
+            f = filter_index
+            mask = _native.filter_mask(f.query_keys(src, rel), f.keys, f.ptr, f.tails, ent.size(0))
+            counts = _native.score_rank(x, ent, self.conv2.bias, obj, target, mask=mask)
         return counts, target

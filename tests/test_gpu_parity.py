@@ -255,3 +255,73 @@ def test_cpu_tensors_fail_loudly(pkg):
     with pytest.raises(pkg._native.NativeError):
         pkg._native.aggregate_fwd(csr, sd['entity_embedding'], torch.cat([sd['relation_embedding'], sd['conv1.loop_rel']]),
                                   None, True, None, torch.empty(7, 32))
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_device_filter_bits_equal_dense_labels(pkg, case):
+    """the filter built on the device from the (s, r) -> tails index gives exactly the counts of the
+    dense label rows the reference loader ships (data_loader.py:34-51)."""
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    model.eval()
+    filt = dl.filter_index().to(DEV)
+    for split in ('valid_tail', 'valid_head', 'test_tail', 'test_head'):
+        trip = g.t('dl_q_%s_triple' % split).to(DEV)
+        ds = dl._get_dataset(split, params)
+        label = torch.stack([ds[i][1] for i in range(len(ds))]).to(DEV)
+        obj = trip[:, 2].contiguous()
+        c_dense, t_dense = model.rank_counts(trip[:, 0], trip[:, 1], obj, label, dl.graph)
+        c_bits, t_bits = model.rank_counts(trip[:, 0], trip[:, 1], obj, None, dl.graph, filter_index=filt)
+        assert torch.equal(c_dense, c_bits) and torch.equal(t_dense, t_bits)
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_evaluate_sharded_world1_vs_golden(pkg, case):
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    filt = dl.filter_index().to(DEV)
+    for split in ('valid', 'test'):
+        res = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries(split), filt, batch_size=g.hp['batch_size'])
+        ref = pkg.harness.evaluate(model, dl.get_data_loaders(g.hp['batch_size'], 0, params), dl.graph, params, split)
+        assert abs(res['mrr'] - float(ref['mrr'])) < 1e-5 and abs(res['mr'] - float(ref['mr'])) < 1e-3
+        assert abs(res['mrr'] - float(g['evaluate_%s_mrr' % split])) <= 1e-4
+
+
+def _sharded_worker(rank, world, port, case, q):
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # both ranks share cuda:0; gloo stages via host
+    pkg = importlib.import_module('kgc-gcn_amd')
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    filt = dl.filter_index().to(DEV)
+    res = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries('test'), filt, batch_size=7)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_sharded_two_ranks_one_gpu(pkg):
+    """Two processes, entity table split in two row shards, collectives over gloo: identical metrics on both ranks,
+    equal to the single-process evaluation (integer counts add up exactly)."""
+    import torch.multiprocessing as mp
+    case, world, port = 'syn_b', 2, 29600 + os.getpid() % 2000
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    want = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries('test'), dl.filter_index().to(DEV), batch_size=7)
+    for r in range(world):
+        assert got[r]['count'] == want['count']
+        for k in ('mr', 'mrr', 'hits@1', 'hits@3', 'hits@10'):
+            assert abs(got[r][k] - want[k]) < 1e-12, (r, k)
