@@ -74,12 +74,18 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; the modulo only matters when a multi-rank run is REHEARSED on a box with fewer GPUs
+    # (MGCN_DIST_BACKEND=gloo, ranks sharing a card) — on the 8-GPU node it is the identity
+    dev = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get('MGCN_DIST_BACKEND', 'nccl'), device_id=dev)
+        backend = os.environ.get('MGCN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module('kgc-gcn_amd')
     shape = SHAPES[args.shape]
@@ -136,13 +142,24 @@ def main():
         'config': {'workload': '%s-shape synthetic graph (N=%d, R=%d, E=%d), %d-layer M-GCN encoder %s, full-graph '
                                'forward, eval mode' % (args.shape, N, R, E, args.layers,
                                                        '->'.join(map(str, [D] + [O] * args.layers))),
-                   'edges_per_step_per_gpu': edges_per_step, 'parallelism': 'graph-per-gpu x%d' % world},
+                   'edges_per_step_per_gpu': edges_per_step,
+                   'parallelism': 'one graph of this shape per GPU x%d, no data-path collective in the encoder step; '
+                                  'the RCCL exchange of the sharded scoring pass is timed in "eval"' % world},
     }
 
     if rank == 0:
         result.update(kernel_breakdown(pkg, model, graph, args, N, R, E, D, O))
-        if not args.no_eval:
-            result['eval'] = eval_wallclock(pkg, model, graph, params, shape, dev)
+    if not args.no_eval:                                    # every rank takes part (collectives when W > 1)
+        if rank != 0:                                       # the sharded pass needs ONE graph on all ranks: rank 0's
+            edge_index, edge_attr = synth_graph(shape, seed=0)
+            graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
+            graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
+            graph.to(dev)
+            model._slot_csr = None                          # tables are synthetic: re-lay them out for this graph
+        ev = eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank)
+        if rank == 0:
+            result['eval'] = ev
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O)
             result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
@@ -150,7 +167,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
@@ -225,50 +243,66 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
     return {'roofline': roof, 'kernels': kern}
 
 
-def eval_wallclock(pkg, model, graph, params, shape, dev):
-    """Full filtered-MRR evaluation wall-clock: 2 x n_eval queries in batches of 128 against all N entities,
-    query blocks and label rows already on the device. `fused` = HIP score+filter+count kernel, encoder computed
-    once (eval-mode cache); `reference_order` = encoder recomputed per batch, [B,N] scores + double argsort."""
-    N = shape['N']
+def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank):
+    """Full filtered-MRR evaluation wall-clock: 2 x n_eval queries (tail + head side) in batches of 128 against all
+    N entities. Three forms of the same computation, each timed on its second run:
+      sharded_bits_s    dist.evaluate_sharded: encoder once (eval cache), filter bits built on the device, HIP
+                        score+filter+count kernel, entity table row-sharded over the ranks (RCCL exchange if W > 1);
+      fused_dense_s     (rank 0 only) HIP kernel fed by dense [B, N] label blocks already resident on the device;
+      reference_order_s (rank 0 only) what main.py:117-126 does: encoder per batch, [B, N] scores, double argsort."""
+    N, R = shape['N'], shape['R']
     n_eval = min(shape['n_eval'], 4096)
     rng = np.random.default_rng(7)
     B = 128
-    batches = []
-    for side in range(2):
-        for i in range(0, n_eval, B):
-            b = min(B, n_eval - i)
-            trip = torch.from_numpy(np.stack((rng.integers(0, N, b), rng.integers(0, 2 * shape['R'], b),
-                                              rng.integers(0, N, b)), axis=1)).to(dev)
-            lab = torch.zeros((b, N), device=dev)
-            extra = torch.from_numpy(rng.integers(0, N, (b, 4))).to(dev)
-            lab.scatter_(1, extra, 1.0)
-            lab.scatter_(1, trip[:, 2:3], 1.0)
-            batches.append((trip, lab))
-    out = {'queries': 2 * n_eval, 'batch': B}
-    with torch.no_grad():                                   # warm every code path once (MIOpen find, code load)
-        trip, lab = batches[0]
-        model.rank_counts(trip[:, 0], trip[:, 1], trip[:, 2].contiguous(), lab, graph)
-        pkg.harness.ranks_from_scores(model(trip[:, 0], trip[:, 1], graph), lab, trip[:, 2])
-    for name, fused, cache in (('fused_cached_s', True, True), ('fused_recompute_s', True, False),
-                               ('reference_order_s', False, False)):
-        params.cache_encoder = cache
+    s = rng.integers(0, N, 2 * n_eval)
+    r = rng.integers(0, 2 * R, 2 * n_eval)
+    o = rng.integers(0, N, 2 * n_eval)
+    queries = torch.from_numpy(np.stack((s, r, o), axis=1))
+    known = {}
+    ei, et = edge_index.numpy(), edge_attr[0].numpy()
+    for a, t, bb in zip(ei[0], et, ei[1]):                   # every training edge (both directions) is a known answer
+        known.setdefault((int(a), int(t)), set()).add(int(bb))
+    for a, t, bb in zip(s, r, o):
+        known.setdefault((int(a), int(t)), set()).add(int(bb))
+    filt = pkg.dist.FilterIndex.from_known(known, 2 * R).to(dev)
+    out = {'queries': 2 * n_eval, 'batch': B, 'world': world}
+    params.cache_encoder = True
+    for _ in range(2):
         model._enc_cache = None
-        mrr = 0.0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.no_grad():
-            acc = torch.zeros((), dtype=torch.float64, device=dev)
-            for trip, lab in batches:
-                if fused:
-                    counts, _ = model.rank_counts(trip[:, 0], trip[:, 1], trip[:, 2].contiguous(), lab, graph)
-                    ranks = 1 + counts[:, 0] + counts[:, 1]
-                else:
-                    ranks = pkg.harness.ranks_from_scores(model(trip[:, 0], trip[:, 1], graph), lab, trip[:, 2])
-                acc += (1.0 / ranks.double()).sum()
-            mrr = float(acc.item()) / (2 * n_eval)
+        res = pkg.dist.evaluate_sharded(model, graph, queries, filt, batch_size=B)
         torch.cuda.synchronize()
-        out[name] = time.perf_counter() - t0
-        out[name.replace('_s', '_mrr')] = mrr
+        out['sharded_bits_s'] = time.perf_counter() - t0
+    out['sharded_bits_mrr'] = res['mrr']
+    if rank == 0:
+        batches = []
+        for i in range(0, 2 * n_eval, B):
+            q = queries[i:i + B].to(dev)
+            keys = filt.query_keys(q[:, 0], q[:, 1])
+            mask = pkg._native.filter_mask(keys, filt.keys, filt.ptr, filt.tails, N)
+            bits = (mask.view(torch.int32)[:, :, None] >> torch.arange(32, device=dev, dtype=torch.int32)) & 1
+            lab = bits.reshape(q.size(0), -1)[:, :N].float().contiguous()
+            batches.append((q, lab))
+        for name, fused, cache in (('fused_dense_s', True, True), ('reference_order_s', False, False)):
+            params.cache_encoder = cache
+            for _ in range(2):
+                model._enc_cache = None
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    acc = torch.zeros((), dtype=torch.float64, device=dev)
+                    for q, lab in batches:
+                        if fused:
+                            counts, _ = model.rank_counts(q[:, 0], q[:, 1], q[:, 2].contiguous(), lab, graph)
+                            ranks = 1 + counts[:, 0] + counts[:, 1]
+                        else:
+                            ranks = pkg.harness.ranks_from_scores(model(q[:, 0], q[:, 1], graph), lab, q[:, 2])
+                        acc += (1.0 / ranks.double()).sum()
+                    mrr = float(acc.item()) / (2 * n_eval)
+                torch.cuda.synchronize()
+                out[name] = time.perf_counter() - t0
+            out[name.replace('_s', '_mrr')] = mrr
     params.cache_encoder = False
     model._enc_cache = None
     return out
