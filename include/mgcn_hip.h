@@ -127,6 +127,22 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
                            const float *bn_gamma_dev, const float *bn_beta_dev, float bn_eps,
                            float *out_dev, int64_t ldo, void *stream);
 
+/* (2)+(4) in ONE launch (eval mode): out = tanh(BN_eval((A_in W_in + A_out W_out + A_loop W_loop)/3 + bias)) with
+ * the aggregates of (2) built per 32-destination tile in LDS and consumed by the MFMA step of (4) without ever
+ * reaching HBM. Arguments as in (2) and (4); w_dev is the stacked [3*dim_in, dim_out] weight, re-packed per call
+ * into MFMA-fragment order in workspace_dev (mgcn_layer_fused_workspace bytes, 16-byte aligned). Returns
+ * MGCN_EUNSUPPORTED (and does nothing) unless all operands are 16-byte aligned, dim_in % 4 == 0, dim_in <= 256,
+ * dim_out % 4 == 0 and dim_out <= 208 — callers then use (2) followed by (4). */
+int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
+                         int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
+                         const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
+                         const float *ee_dev, int32_t ee_in_slot_order, const float *loop_edge_dev,
+                         const float *w_dev, const float *bias_dev, const float *bn_mean_dev,
+                         const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
+                         float bn_eps, float *out_dev, int64_t ldo, float *workspace_dev, size_t workspace_bytes,
+                         void *stream);
+size_t mgcn_layer_fused_workspace(int32_t dim_in, int32_t dim_out);
+
 /* Plain C[M,N] = A[M,K] @ B[K,N] on the same f32 MFMA kernel (model.py:107, the relation projection). */
 int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t lda, const float *b_dev,
                     int64_t ldb, float *c_dev, int64_t ldc, void *stream);

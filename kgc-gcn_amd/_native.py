@@ -27,6 +27,10 @@ _SIGNATURES = {
                                           _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
+    'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
+                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr,
+                                            ctypes.c_size_t, _ptr]),
+    'mgcn_layer_fused_workspace': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
@@ -192,6 +196,42 @@ def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, o
         _dev(bn_var, torch.float32, 'bn_var'), _dev(bn_gamma, torch.float32, 'bn_gamma'),
         _dev(bn_beta, torch.float32, 'bn_beta'), float(eps), _dev(out, torch.float32, 'out'), _ld(out), _stream(a)),
         'mgcn_dense_bn_tanh_fwd')
+    return out
+
+
+def fused_supported(d_in, d_out):
+    """Shapes the one-launch layer kernel handles (else: aggregate_fwd + dense_bn_tanh_fwd)."""
+    return (os.environ.get('MGCN_FUSED', '1') != '0' and d_in % 4 == 0 and d_in <= 256 and d_out % 4 == 0
+            and d_out <= 208)
+
+
+def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_cat, bias, bn_mean, bn_var, bn_gamma,
+                    bn_beta, eps, out):
+    """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ w_cat) / 3 + bias)), aggregates kept in LDS."""
+    N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), w_cat.size(1)
+    _same_device(csr.rowptr, x, rel, loop_rel, ee, loop_edge, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
+    if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows - 1, D) or loop_rel.numel() != D or loop_edge.numel() != D:
+        raise NativeError('layer_fwd_fused: x / rel / loop rows do not match the graph')
+    if ee is not None and (tuple(ee.shape) != (2 * E, D) or not ee.is_contiguous()):
+        raise NativeError('layer_fwd_fused: per-edge table must be contiguous (%d, %d)' % (2 * E, D))
+    if tuple(w_cat.shape) != (3 * D, O) or not w_cat.is_contiguous() or not rel.is_contiguous():
+        raise NativeError('layer_fwd_fused: w_cat must be contiguous (3D, O), rel contiguous')
+    for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
+        if v.numel() != O:
+            raise NativeError('layer_fwd_fused: per-column vectors must have %d elements' % O)
+    if tuple(out.shape) != (N, O):
+        raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (N, O))
+    ws_bytes = lib().mgcn_layer_fused_workspace(D, O)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    _check(lib().mgcn_layer_fwd_fused(
+        N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
+        _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
+        _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge'),
+        _dev(w_cat, torch.float32, 'w_cat'), _dev(bias, torch.float32, 'bias', True),
+        _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
+        _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
+        _dev(out, torch.float32, 'out'), _ld(out), _dev(ws, torch.float32, 'workspace'), ws_bytes, _stream(x)),
+        'mgcn_layer_fwd_fused')
     return out
 
 

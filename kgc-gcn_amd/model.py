@@ -79,7 +79,7 @@ class MGCNConv(nn.Module):
         """[W_in; W_out; W_loop] as one [3D, O] matrix for the fused dense step; rebuilt only when a weight changed."""
         ws = (self.in_weight, self.out_weight, self.loop_weight)
         stamp = tuple((w._version, w.data_ptr()) for w in ws)
-        if torch.cuda.is_current_stream_capturing():
+        if self.in_weight.is_cuda and torch.cuda.is_current_stream_capturing():
             return torch.cat([w.detach() for w in ws], dim=0)      # part of the captured graph: re-stacked per replay
         if getattr(self, '_wcat_stamp', None) != stamp:
             self._wcat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
@@ -108,13 +108,18 @@ class MGCNConv(nn.Module):
             or any(p.requires_grad for p in self.parameters()))
         x = x.contiguous()
         if not self.training and not tracked:
-            agg = torch.empty((num_ent, 3 * self.in_channels), dtype=torch.float32, device=x.device)
-            _native.aggregate_fwd(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order,
-                                  self.loop_edge.reshape(-1), agg, loop_rel=self.loop_rel.reshape(-1))
             all_ent = torch.empty((num_ent, self.out_channels), dtype=torch.float32, device=x.device)
             bn = self.ent_bn
-            _native.dense_bn_tanh_fwd(agg, self.stacked_weight(), self.bias, bn.running_mean, bn.running_var,
-                                      bn.weight, bn.bias, bn.eps, all_ent)
+            if _native.fused_supported(self.in_channels, self.out_channels):
+                _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
+                                        ee_in_slot_order, self.loop_edge.reshape(-1), self.stacked_weight(), self.bias,
+                                        bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
+            else:
+                agg = torch.empty((num_ent, 3 * self.in_channels), dtype=torch.float32, device=x.device)
+                _native.aggregate_fwd(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order,
+                                      self.loop_edge.reshape(-1), agg, loop_rel=self.loop_rel.reshape(-1))
+                _native.dense_bn_tanh_fwd(agg, self.stacked_weight(), self.bias, bn.running_mean, bn.running_var,
+                                          bn.weight, bn.bias, bn.eps, all_ent)
             # (rels @ W)[:-1] drops the self-loop row, so the projection needs no concatenation (model.py:107)
             return all_ent, _native.matmul(rels_embs.contiguous(), self.rels_weight)
 
