@@ -183,17 +183,17 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
     bufs = []
     for layer in layers:
         bufs.append((torch.empty((N, 3 * layer.in_channels), device=model.entity_embedding.device),
-                     torch.empty((N, O), device=model.entity_embedding.device), layer.stacked_weight()))
+                     torch.empty((N, O), device=model.entity_embedding.device), layer.derived_weights()))
 
     def sequence(events):
         x, rel = model.entity_embedding, model.relation_embedding
         i = 0
-        for layer, table, (agg, out, wcat) in zip(layers, tables, bufs):
+        for layer, table, (agg, out, (wcat, wpack)) in zip(layers, tables, bufs):
             bn = layer.ent_bn
             events[i].record(); i += 1
             if fused:
-                nat.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table, True, layer.loop_edge.reshape(-1), wcat,
-                                    layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
+                nat.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table, True, layer.loop_edge.reshape(-1), wpack,
+                                    O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
                 events[i].record(); i += 1
             else:
                 nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1))

@@ -89,12 +89,14 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
  * else in reference edge-id order (gathered through rec.eid); NULL = no per-edge factor.
  *   x_dev [N, D] (ldx floats between rows), rel_dev [num_rel_rows-1, D], loop_edge_dev [D] or NULL
  *   (then the third block is not written and A needs only 2D columns), a_dev [N, lda].
+ * Only destinations [node_begin, node_end) are processed (rows of a_dev indexed by global node id): row chunks
+ * can be pipelined against (4) on another stream, and a destination partition is one rank's share.
  */
 int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                        const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                        int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
                        int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
-                       void *stream);
+                       int64_t node_begin, int64_t node_end, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) Aggregation backward (autograd through (2); driven by main.py:66). Given g = dL/dA [N, lda]
@@ -128,20 +130,21 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
                            float *out_dev, int64_t ldo, void *stream);
 
 /* (2)+(4) in ONE launch (eval mode): out = tanh(BN_eval((A_in W_in + A_out W_out + A_loop W_loop)/3 + bias)) with
- * the aggregates of (2) built per 32-destination tile in LDS and consumed by the MFMA step of (4) without ever
- * reaching HBM. Arguments as in (2) and (4); w_dev is the stacked [3*dim_in, dim_out] weight, re-packed per call
- * into MFMA-fragment order in workspace_dev (mgcn_layer_fused_workspace bytes, 16-byte aligned). Returns
- * MGCN_EUNSUPPORTED (and does nothing) unless all operands are 16-byte aligned, dim_in % 4 == 0, dim_in <= 256,
- * dim_out % 4 == 0 and dim_out <= 208 — callers then use (2) followed by (4). */
+ * the aggregates of (2) built per 32-destination tile in LDS by four gather waves and consumed by four MFMA waves of
+ * the same block without ever reaching HBM. Arguments as in (2) and (4), except that the weights are passed in MFMA
+ * fragment order: wp_dev = mgcn_pack_weights() of the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes
+ * bytes, 16-byte aligned; re-pack whenever a weight changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all
+ * operands are 16-byte aligned, dim_in % 4 == 0, dim_in <= 256, dim_out % 4 == 0 and dim_out <= 208 — callers then
+ * use (2) followed by (4). */
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
                          const float *ee_dev, int32_t ee_in_slot_order, const float *loop_edge_dev,
-                         const float *w_dev, const float *bias_dev, const float *bn_mean_dev,
+                         const float *wp_dev, const float *bias_dev, const float *bn_mean_dev,
                          const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
-                         float bn_eps, float *out_dev, int64_t ldo, float *workspace_dev, size_t workspace_bytes,
-                         void *stream);
-size_t mgcn_layer_fused_workspace(int32_t dim_in, int32_t dim_out);
+                         float bn_eps, float *out_dev, int64_t ldo, void *stream);
+int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
+size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 
 /* Plain C[M,N] = A[M,K] @ B[K,N] on the same f32 MFMA kernel (model.py:107, the relation projection). */
 int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t lda, const float *b_dev,

@@ -22,15 +22,15 @@ _SIGNATURES = {
     'mgcn_last_error': (ctypes.c_char_p, []),
     'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64] + [_ptr] * 10),
     'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
-                                          _ptr, _ptr, _i64, _ptr]),
+                                          _ptr, _ptr, _i64, _i64, _i64, _ptr]),
     'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _i64,
                                           _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
-                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr,
-                                            ctypes.c_size_t, _ptr]),
-    'mgcn_layer_fused_workspace': (ctypes.c_size_t, [_i32, _i32]),
+                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr]),
+    'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
@@ -120,7 +120,7 @@ def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward
     return out
 
 
-def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None):
+def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None):
     """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR.
     `rel` is either the whole relation table [num_rel_rows, D] (last row = self-loop row) or, with
     `loop_rel` [D] given separately, its first num_rel_rows-1 rows (no concatenation needed)."""
@@ -142,11 +142,14 @@ def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=No
         raise NativeError('aggregate_fwd: loop_edge must have %d elements' % D)
     if out.size(0) != N or out.size(1) < modes * D:
         raise NativeError('aggregate_fwd: out %s too small for (%d, %d)' % (tuple(out.shape), N, modes * D))
+    n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
+    if not 0 <= n0 <= n1 <= N:
+        raise NativeError('aggregate_fwd: node range (%d, %d) outside [0, %d]' % (n0, n1, N))
     _check(lib().mgcn_aggregate_fwd(
         N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
-        _dev(out, torch.float32, 'out'), _ld(out), _stream(x)), 'mgcn_aggregate_fwd')
+        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, _stream(x)), 'mgcn_aggregate_fwd')
     return out
 
 
@@ -205,33 +208,47 @@ def fused_supported(d_in, d_out):
             and d_out <= 208)
 
 
-def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_cat, bias, bn_mean, bn_var, bn_gamma,
-                    bn_beta, eps, out):
-    """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ w_cat) / 3 + bias)), aggregates kept in LDS."""
-    N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), w_cat.size(1)
-    _same_device(csr.rowptr, x, rel, loop_rel, ee, loop_edge, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
+def pack_weights(w_cat, out=None):
+    """Stacked [3D, O] weights -> MFMA fragment order for layer_fwd_fused (re-pack whenever a weight changes)."""
+    D, O = w_cat.size(0) // 3, w_cat.size(1)
+    if w_cat.dim() != 2 or w_cat.size(0) != 3 * D or not w_cat.is_contiguous():
+        raise NativeError('pack_weights: w_cat must be contiguous (3D, O)')
+    nbytes = lib().mgcn_packed_weights_bytes(D, O)
+    if out is None:
+        out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_cat.device)
+    if out.numel() * 4 < nbytes:
+        raise NativeError('pack_weights: out too small')
+    _same_device(w_cat, out)
+    _check(lib().mgcn_pack_weights(D, O, _dev(w_cat, torch.float32, 'w_cat'), _dev(out, torch.float32, 'wp'),
+                                   out.numel() * 4, _stream(w_cat)), 'mgcn_pack_weights')
+    return out
+
+
+def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
+                    bn_gamma, bn_beta, eps, out):
+    """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
+    `w_packed` = pack_weights(stacked [3D, O] weights)."""
+    N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), int(d_out)
+    _same_device(csr.rowptr, x, rel, loop_rel, ee, loop_edge, w_packed, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
     if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows - 1, D) or loop_rel.numel() != D or loop_edge.numel() != D:
         raise NativeError('layer_fwd_fused: x / rel / loop rows do not match the graph')
     if ee is not None and (tuple(ee.shape) != (2 * E, D) or not ee.is_contiguous()):
         raise NativeError('layer_fwd_fused: per-edge table must be contiguous (%d, %d)' % (2 * E, D))
-    if tuple(w_cat.shape) != (3 * D, O) or not w_cat.is_contiguous() or not rel.is_contiguous():
-        raise NativeError('layer_fwd_fused: w_cat must be contiguous (3D, O), rel contiguous')
+    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
+        raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:
             raise NativeError('layer_fwd_fused: per-column vectors must have %d elements' % O)
     if tuple(out.shape) != (N, O):
         raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (N, O))
-    ws_bytes = lib().mgcn_layer_fused_workspace(D, O)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     _check(lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge'),
-        _dev(w_cat, torch.float32, 'w_cat'), _dev(bias, torch.float32, 'bias', True),
+        _dev(w_packed, torch.float32, 'w_packed'), _dev(bias, torch.float32, 'bias', True),
         _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
         _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
-        _dev(out, torch.float32, 'out'), _ld(out), _dev(ws, torch.float32, 'workspace'), ws_bytes, _stream(x)),
-        'mgcn_layer_fwd_fused')
+        _dev(out, torch.float32, 'out'), _ld(out), _stream(x)), 'mgcn_layer_fwd_fused')
     return out
 
 

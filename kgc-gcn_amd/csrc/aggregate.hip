@@ -54,6 +54,7 @@ struct AggArgs {
   float *a;
   int64_t ldx, lda;
   int32_t n, e, d, rel_rows, ee_slot_order, modes;
+  int32_t node0, nodes;  // destinations [node0, node0 + nodes) are processed
 };
 
 // GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots in flight per group:
@@ -66,9 +67,9 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   const int gs = 1 << gs_log2;
   const int lane_in_group = threadIdx.x & (gs - 1);
   const int64_t item = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
-  if (item >= int64_t(p.modes) * p.n) return;
-  const int mode = int(item / p.n);
-  const int node = int(item - int64_t(mode) * p.n);
+  if (item >= int64_t(p.modes) * p.nodes) return;
+  const int mode = int(item / p.nodes);
+  const int node = p.node0 + int(item - int64_t(mode) * p.nodes);
   const int nchunk = p.d / VEC;
 
   if (mode == 2) {  // self loop: (x * rel[last]) * loop_edge, model.py:91-94,101
@@ -346,7 +347,7 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
                                   const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                                   int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
                                   int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
-                                  void *stream) {
+                                  int64_t node_begin, int64_t node_end, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_fwd: bad sizes");
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "aggregate_fwd: sizes exceed int32");
@@ -355,7 +356,8 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   MGCN_REQUIRE(num_edges_half == 0 || rec_dev, "aggregate_fwd: null rec");
   const int modes = loop_edge_dev ? 3 : 2;
   MGCN_REQUIRE(ldx >= dim && lda >= int64_t(modes) * dim, "aggregate_fwd: ldx/lda too small");
-  if (num_nodes == 0) return MGCN_OK;
+  MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "aggregate_fwd: bad node range");
+  if (node_end == node_begin) return MGCN_OK;
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
                        mgcn::aligned16(a_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
                        (!loop_edge_dev || mgcn::aligned16(loop_edge_dev)) && ldx % 4 == 0 && lda % 4 == 0;
@@ -378,8 +380,10 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   p.rel_rows = num_rel_rows;
   p.ee_slot_order = ee_in_slot_order;
   p.modes = modes;
+  p.node0 = int32_t(node_begin);
+  p.nodes = int32_t(node_end - node_begin);
   {
-    const int64_t threads = (int64_t(modes) * num_nodes) << g.gs_log2;
+    const int64_t threads = (int64_t(modes) * p.nodes) << g.gs_log2;
     const unsigned grid = unsigned((threads + 255) / 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define MGCN_FWD_CASE(V_, C_, U_) hipLaunchKernelGGL((agg_fwd_kernel<V_, C_, U_>), dim3(grid), dim3(256), 0, st, p, g.gs_log2)

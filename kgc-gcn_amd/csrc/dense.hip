@@ -441,241 +441,6 @@ __global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused layer forward (eval): aggregation + dense step + epilogue in ONE launch; the [N, 3D] aggregate never
-// leaves the CU. Block = 8 waves on one 32-destination tile, two roles:
-//   waves 4-7  GATHER   lane groups (25 of 32 lanes x dwordx4 for D = 100) each own a run of consecutive
-//              destinations; the run's slots are ONE contiguous CSR range walked U at a time (records, then
-//              3*U row loads, then the arithmetic in slot order: the same sums as agg_fwd_kernel, bit for bit).
-//              Finished rows go to the LDS tile As[mode & 1][32][D+2] (row stride / 2 odd => conflict-free
-//              ds_read_b32 of the A fragments).
-//   waves 0-3  MFMA     acc += As . W_mode with v_mfma_f32_16x16x4_f32. W comes straight from global memory
-//              (L2-resident) in a pre-packed fragment order (pack_w_kernel): one dwordx4 per (k-block, column
-//              tile, lane) holds the lane's B values of the block's four MFMA steps; loads run one k-block
-//              ahead. No weight slab in LDS, hence no barrier inside a mode.
-// The two roles are a 4-stage pipeline over the modes (in-half, out-half, self-loop): while the MFMA waves
-// multiply mode m, the gather waves fetch mode m+1; one workgroup barrier per stage. Two blocks per CU.
-struct FusedArgs {
-  const int32_t *rowptr;
-  const int4 *rec;
-  const float *x, *rel, *loop_rel, *ee, *loop_edge;
-  const float4 *wp;  // packed weights [3][nkb][NT][64] float4
-  const float *bias, *bn_mean, *bn_var, *bn_gamma, *bn_beta;
-  float *out;
-  int64_t ldx, ldo;
-  int32_t n, e, d, o, rel_rows, ee_slot_order, gs_log2;
-  int32_t ablate;  // timing diagnostics only (MGCN_FUSED_ABLATE): bit 0 skips the gather, bit 1 the MFMA loop
-  float bn_eps;
-};
-
-__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-
-// wp[((mode*nkb + kb)*nt + ct)*64 + lane].{x,y,z,w}[i] = W[mode*D + 16kb + 4i + (lane>>4)][16ct + (lane&15)], 0 outside
-__global__ __launch_bounds__(256) void pack_w_kernel(const float *__restrict__ w, float4 *__restrict__ wp, int d, int o,
-                                                     int nkb, int nt) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 3 * nkb * nt * 64) return;
-  const int lane = idx & 63, ct = (idx >> 6) % nt, kb = ((idx >> 6) / nt) % nkb, mode = (idx >> 6) / (nt * nkb);
-  const int col = ct * 16 + (lane & 15);
-  float v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = kb * KS + 4 * i + (lane >> 4);
-    v[i] = (k < d && col < o) ? w[(int64_t(mode) * d + k) * o + col] : 0.f;
-  }
-  wp[idx] = make_float4(v[0], v[1], v[2], v[3]);
-}
-
-constexpr int FUSED_THREADS = 512;
-
-template <int NT>
-__global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs p) {
-  constexpr int LDO = NT * 16 + 4;     // staging row stride (floats)
-  constexpr int NTW = (NT + 1) / 2;
-  constexpr int U = 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lda = p.d + 2;
-  float *As = lds;                                        // [2][BM][lda]; reused as [BM][LDO] output staging
-  const int as_floats = (2 * BM * lda > BM * LDO) ? 2 * BM * lda : BM * LDO;
-  int *rps = reinterpret_cast<int *>(lds + as_floats);    // [2][BM + 1] slot positions of the tile's rows
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const bool mfma_role = wave < 4;
-  const int r0 = int(blockIdx.x) * BM;
-  const int nkb = (p.d + KS - 1) / KS;
-
-  if (tid < 2 * (BM + 1)) {
-    const int h = tid / (BM + 1), i = tid - h * (BM + 1);
-    const int node = (r0 + i < p.n) ? r0 + i : p.n;
-    rps[tid] = p.rowptr[int64_t(h) * (p.n + 1) + node];
-  }
-
-  // ---- MFMA-role state ----
-  const int rt = wave & 1, ch = (wave >> 1) & 1;
-  const int ct0 = ch * NTW;
-  const int nct = ch == 0 ? NTW : NT - NTW;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[NTW];
-  float4 wcur[NTW];
-  if (mfma_role) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int ct = (t < nct) ? ct0 + t : ct0;
-      wcur[t] = p.wp[int64_t(ct) * 64 + lane];   // (mode 0, kb 0): in flight across the first barrier
-    }
-  }
-  // ---- gather-role state ----
-  const int gtid = tid - 256;
-  const int gs = 1 << p.gs_log2;
-  const int grp = gtid >> p.gs_log2, lig = gtid & (gs - 1);
-  const int rpg = (BM * gs) / 256;                 // destinations per group (>= 1)
-  const int g_lo = grp * rpg, g_hi = g_lo + rpg;
-  const bool col_ok = lig * 4 < p.d;
-  const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
-
-  __syncthreads();
-
-  // The two roles are two separate programs (disjoint live ranges -> each fits the register budget); both
-  // execute exactly four workgroup barriers, one per pipeline stage.
-  if (!mfma_role) {
-    for (int mode = 0; mode < 3; ++mode) {
-      float *at = As + (mode & 1) * BM * lda;
-      if (p.ablate & 1) {
-      } else if (mode < 2) {
-        const int *rp = rps + mode * (BM + 1);
-        const int64_t base = int64_t(mode) * p.e;
-        int row = g_lo, nb = rp[g_lo + 1];
-        const int end = rp[g_hi];
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = rp[g_lo]; s < end; s += U) {
-          int4 r[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) r[u] = p.rec[base + ((s + u < end) ? s + u : end - 1)];
-          float4 xv[U], rv[U], ev[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(r[u].x) * p.ldx + coff);
-            const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
-            rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
-            if (p.ee) {
-              const int64_t slot = base + ((s + u < end) ? s + u : end - 1);
-              ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d + coff);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (s + u < end) {
-              while (s + u >= nb) {  // group-uniform: the run of destination `row` is complete
-                if (col_ok) {
-                  float *dst = at + row * lda + lig * 4;
-                  *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
-                  *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
-                }
-                sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                ++row;
-                nb = rp[row + 1];
-              }
-              float4 m = f4mul(xv[u], rv[u]);
-              if (p.ee) m = f4mul(m, ev[u]);
-              const float wgt = __int_as_float(r[u].z);
-              sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
-            }
-          }
-        }
-        for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
-          if (col_ok) {
-            float *dst = at + row * lda + lig * 4;
-            *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
-          }
-          sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101
-        const float4 lr = *reinterpret_cast<const float4 *>(p.loop_rel + coff);
-        const float4 le = *reinterpret_cast<const float4 *>(p.loop_edge + coff);
-        for (int row = g_lo; row < g_hi; ++row) {
-          const int node = (r0 + row < p.n) ? r0 + row : p.n - 1;  // rows past N are computed and never stored
-          const float4 v = f4mul(f4mul(*reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff), lr), le);
-          if (col_ok) {
-            float *dst = at + row * lda + lig * 4;
-            *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
-          }
-        }
-      }
-      __syncthreads();  // stage `mode` done: As[mode & 1] is complete
-    }
-    __syncthreads();    // stage 3 (the MFMA waves multiply the last mode)
-  } else {
-    __syncthreads();    // stage 0 (the gather waves fetch the first mode)
-    for (int mode = 0; mode < 3; ++mode) {
-      const float *arow = As + (mode & 1) * BM * lda + (rt * 16 + fr) * lda + fq;
-      for (int kb = 0; kb < ((p.ablate & 2) ? 0 : nkb); ++kb) {
-        // next k-block's fragments (or the next mode's first block): one k-block ahead of the MFMAs
-        float4 wnext[NTW];
-        int nm = mode, nk = kb + 1;
-        if (nk == nkb) { nm = mode + 1; nk = 0; }
-        if (nm < 3) {
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const int ct = (t < nct) ? ct0 + t : ct0;
-            wnext[t] = p.wp[(int64_t(nm * nkb + nk) * NT + ct) * 64 + lane];
-          }
-        }
-        const int left = (p.d - kb * KS) >> 2;
-        const int nsteps = left < 4 ? left : 4;  // uniform: MFMA steps of 4 k in this block
-        float a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (i < nsteps) ? arow[kb * KS + 4 * i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < nsteps) {
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-              const float bv = i == 0 ? wcur[t].x : i == 1 ? wcur[t].y : i == 2 ? wcur[t].z : wcur[t].w;
-              if (t < nct) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv, acc[t], 0, 0, 0);
-            }
-          }
-        }
-        if (nm < 3) {
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) wcur[t] = wnext[t];
-        }
-      }
-      __syncthreads();  // stage mode+1 done
-    }
-  }
-
-  // ---------------- epilogue: /3, bias, BN(eval), tanh; staged through LDS, 16-byte row stores ----------------
-  float *os = As;
-  if (mfma_role) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = (ct0 + t) * 16 + fr;
-      if (t >= nct || col >= p.o) continue;
-      const float cb = p.bias ? p.bias[col] : 0.f;
-      const float mean = p.bn_mean[col];
-      const float inv = 1.0f / sqrtf(p.bn_var[col] + p.bn_eps);
-      const float gam = p.bn_gamma[col], bet = p.bn_beta[col];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = acc[t][j] / 3.0f;
-        if (p.bias) v = v + cb;
-        os[(rt * 16 + fq * 4 + j) * LDO + col] = tanhf_((v - mean) * inv * gam + bet);
-      }
-    }
-  }
-  __syncthreads();
-  const int c4n = p.o >> 2;
-  for (int s4 = tid; s4 < BM * c4n; s4 += FUSED_THREADS) {
-    const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-    if (r0 + lrow < p.n)
-      *reinterpret_cast<float4 *>(p.out + int64_t(r0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(os + lrow * LDO + lc);
-  }
-}
-
 // all_rel = rels_embs @ rels_weight (model.py:107 without the dropped last row): [T, K] x [K, O], T tiny, so
 // the kernel is pure latency. Block = (one output row, 64 columns); its 4 waves split K and keep UNR
 // independent loads in flight per lane; partial sums meet in LDS and are added in wave order.
@@ -882,65 +647,3 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
 }
 
-extern "C" size_t mgcn_layer_fused_workspace(int32_t dim_in, int32_t dim_out) {
-  const int nkb = (dim_in + KS - 1) / KS, nt = pick_nt(dim_out);
-  return size_t(3) * nkb * nt * 64 * sizeof(float4);
-}
-
-extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
-                                    int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
-                                    const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
-                                    const float *ee_dev, int32_t ee_in_slot_order, const float *loop_edge_dev,
-                                    const float *w_dev, const float *bias_dev, const float *bn_mean_dev,
-                                    const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
-                                    float bn_eps, float *out_dev, int64_t ldo, float *workspace_dev,
-                                    size_t workspace_bytes, void *stream) {
-  MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
-               "layer_fwd_fused: bad sizes");
-  MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 64 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
-               "layer_fwd_fused: sizes exceed int32");
-  MGCN_REQUIRE(rowptr_dev && x_dev && loop_rel_dev && loop_edge_dev && w_dev && bn_mean_dev && bn_var_dev &&
-                   bn_gamma_dev && bn_beta_dev && out_dev && workspace_dev && (rel_dev || num_rel_rows == 1) &&
-                   (num_edges_half == 0 || rec_dev), "layer_fwd_fused: null pointer");
-  MGCN_REQUIRE(ldx >= dim_in && ldo >= dim_out, "layer_fwd_fused: ldx/ldo too small");
-  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
-                       mgcn::aligned16(loop_edge_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
-                       mgcn::aligned16(out_dev) && mgcn::aligned16(workspace_dev) && ldx % 4 == 0 && ldo % 4 == 0;
-  if (!aligned || dim_in % 4 != 0 || dim_in > 256 || dim_out % 4 != 0 || dim_out > 208)
-    return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, D %% 4 == 0, D <= 256, "
-                      "O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
-  MGCN_REQUIRE(workspace_bytes >= mgcn_layer_fused_workspace(dim_in, dim_out), "layer_fwd_fused: workspace too small");
-  if (num_nodes == 0) return MGCN_OK;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nkb = (dim_in + KS - 1) / KS, nt = pick_nt(dim_out);
-  {
-    const int total = 3 * nkb * nt * 64;
-    hipLaunchKernelGGL(pack_w_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, st, w_dev,
-                       reinterpret_cast<float4 *>(workspace_dev), dim_in, dim_out, nkb, nt);
-    MGCN_CHECK_LAUNCH("pack_w_kernel");
-  }
-  FusedArgs p = {};
-  p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
-  p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;
-  p.wp = reinterpret_cast<const float4 *>(workspace_dev);
-  p.bias = bias_dev; p.bn_mean = bn_mean_dev; p.bn_var = bn_var_dev; p.bn_gamma = bn_gamma_dev; p.bn_beta = bn_beta_dev;
-  p.out = out_dev; p.ldx = ldx; p.ldo = ldo;
-  p.n = int32_t(num_nodes); p.e = int32_t(num_edges_half); p.d = dim_in; p.o = dim_out; p.rel_rows = num_rel_rows;
-  p.ee_slot_order = ee_in_slot_order; p.bn_eps = bn_eps;
-  if (const char *ab = getenv("MGCN_FUSED_ABLATE")) p.ablate = atoi(ab);
-  int gl = 3;  // lanes per gather group: smallest power of two >= D/4, at least 8 (so 32 rows cover <= 32 groups)
-  while ((1 << gl) * 4 < dim_in) ++gl;
-  p.gs_log2 = gl;
-  const unsigned grid = unsigned((num_nodes + BM - 1) / BM);
-  const int lda = dim_in + 2, ldo_s = nt * 16 + 4;
-  const size_t as_floats = size_t(2) * BM * lda > size_t(BM) * ldo_s ? size_t(2) * BM * lda : size_t(BM) * ldo_s;
-  const size_t lds_bytes = as_floats * 4 + 2 * (BM + 1) * 4;
-  switch (nt) {
-    case 2: hipLaunchKernelGGL((layer_fused_kernel<2>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
-    case 4: hipLaunchKernelGGL((layer_fused_kernel<4>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
-    case 8: hipLaunchKernelGGL((layer_fused_kernel<8>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
-    default: hipLaunchKernelGGL((layer_fused_kernel<13>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
-  }
-  MGCN_CHECK_LAUNCH("layer_fused_kernel");
-  return MGCN_OK;
-}

@@ -21,6 +21,10 @@ from .graph import csr_for_tensors
 from .utils import get_param
 
 
+def _capturing(t):
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
+
+
 class _AggregateFn(torch.autograd.Function):
     """A[:, :D] / A[:, D:2D] = in-/out-half aggregates; gradients by the HIP backward kernels."""
 
@@ -75,16 +79,62 @@ class MGCNConv(nn.Module):
         self.loop_edge = get_param((1, in_channels))
         self.register_parameter('bias', nn.Parameter(torch.zeros(out_channels)) if bias is True else None)
 
-    def stacked_weight(self):
-        """[W_in; W_out; W_loop] as one [3D, O] matrix for the fused dense step; rebuilt only when a weight changed."""
+    def derived_weights(self):
+        """(stacked, packed): [W_in; W_out; W_loop] as one [3D, O] matrix for the dense launch, and the same in MFMA
+        fragment order for the fused launch (None when the shape is not fused). Both live in PERSISTENT buffers that
+        are refreshed in place only when a weight's version changed, so a captured hipGraph keeps valid pointers;
+        MGCN refreshes them before every replay, outside the capture."""
         ws = (self.in_weight, self.out_weight, self.loop_weight)
         stamp = tuple((w._version, w.data_ptr()) for w in ws)
-        if self.in_weight.is_cuda and torch.cuda.is_current_stream_capturing():
-            return torch.cat([w.detach() for w in ws], dim=0)      # part of the captured graph: re-stacked per replay
-        if getattr(self, '_wcat_stamp', None) != stamp:
-            self._wcat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
-            self._wcat_stamp = stamp
-        return self._wcat
+        if getattr(self, '_derived_stamp', None) != stamp:
+            cat = torch.cat([w.detach() for w in ws], dim=0)
+            if getattr(self, '_wcat', None) is None or self._wcat.shape != cat.shape or self._wcat.device != cat.device:
+                self._wcat, self._wpack = cat.contiguous(), None
+            else:
+                self._wcat.copy_(cat)
+            if self._wcat.is_cuda and _native.fused_supported(self.in_channels, self.out_channels):
+                self._wpack = _native.pack_weights(self._wcat, out=self._wpack)
+            self._derived_stamp = stamp
+        return self._wcat, self._wpack
+
+    def stacked_weight(self):
+        return self.derived_weights()[0]
+
+    def _two_launch_layer(self, csr, x, rels, ee, ee_in_slot_order, all_ent):
+        """Aggregation launch + dense launch. Opt-in experiment MGCN_PIPELINE_CHUNKS = C > 1: rows cut into C chunks,
+        the two kinds of launch on two streams, chunk c's dense step waiting only for chunk c's aggregation.
+        Measured on MI355X / ROCm 7.2 it LOSES: every cross-stream dependency costs ~30 us inside a hipGraph
+        (373 us -> 542 / 820 / 1403 us per step at C = 4 / 8 / 16), so the default is one chunk."""
+        import os
+        n, d = x.size(0), self.in_channels
+        bn = self.ent_bn
+        agg = torch.empty((n, 3 * d), dtype=torch.float32, device=x.device)
+        w = self._wcat if _capturing(x) else self.stacked_weight()
+        le, lr = self.loop_edge.reshape(-1), self.loop_rel.reshape(-1)
+        chunks = int(os.environ.get('MGCN_PIPELINE_CHUNKS', '1'))   # measured: > 1 is slower on ROCm 7.2 (DESIGN.md §4)
+        if chunks <= 1 or n < 64 * chunks:
+            _native.aggregate_fwd(csr, x, rels, ee, ee_in_slot_order, le, agg, loop_rel=lr)
+            _native.dense_bn_tanh_fwd(agg, w, self.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
+            return
+        main = torch.cuda.current_stream(x.device)
+        if getattr(self, '_side_stream', None) is None or self._side_stream.device != x.device:
+            self._side_stream = torch.cuda.Stream(device=x.device)
+        side = self._side_stream
+        side.wait_stream(main)                                  # operands produced on the main stream are ready
+        step = ((n + chunks - 1) // chunks + 31) // 32 * 32     # whole 32-row tiles per chunk
+        for lo in range(0, n, step):
+            hi = min(lo + step, n)
+            with torch.cuda.stream(side):
+                _native.aggregate_fwd(csr, x, rels, ee, ee_in_slot_order, le, agg, loop_rel=lr, node_range=(lo, hi))
+                done = torch.cuda.Event()
+                done.record(side)
+            main.wait_event(done)
+            _native.dense_bn_tanh_fwd(agg[lo:hi], w, self.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                      bn.eps, all_ent[lo:hi])
+        side.wait_stream(main)                                  # `agg` may be freed/reused only after its readers ran
+        if not _capturing(x):
+            for t in (agg, x, rels, ee, w):
+                t.record_stream(side)
 
     def compute_norm(self, edge_index, num_ent):
         """deg^-1/2[row] * deg^-1/2[col], degrees counted by source (model.py:72-80). The layer itself reads
@@ -110,16 +160,13 @@ class MGCNConv(nn.Module):
         if not self.training and not tracked:
             all_ent = torch.empty((num_ent, self.out_channels), dtype=torch.float32, device=x.device)
             bn = self.ent_bn
-            if _native.fused_supported(self.in_channels, self.out_channels):
+            wcat, wpack = (self._wcat, self._wpack) if _capturing(x) else self.derived_weights()
+            if wpack is not None:
                 _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
-                                        ee_in_slot_order, self.loop_edge.reshape(-1), self.stacked_weight(), self.bias,
+                                        ee_in_slot_order, self.loop_edge.reshape(-1), wpack, self.out_channels, self.bias,
                                         bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
             else:
-                agg = torch.empty((num_ent, 3 * self.in_channels), dtype=torch.float32, device=x.device)
-                _native.aggregate_fwd(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order,
-                                      self.loop_edge.reshape(-1), agg, loop_rel=self.loop_rel.reshape(-1))
-                _native.dense_bn_tanh_fwd(agg, self.stacked_weight(), self.bias, bn.running_mean, bn.running_var,
-                                          bn.weight, bn.bias, bn.eps, all_ent)
+                self._two_launch_layer(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order, all_ent)
             # (rels @ W)[:-1] drops the self-loop row, so the projection needs no concatenation (model.py:107)
             return all_ent, _native.matmul(rels_embs.contiguous(), self.rels_weight)
 
@@ -295,6 +342,8 @@ class MGCN(nn.Module):
         output tensors are owned by the capture and are overwritten by the next replay."""
         key = (id(csr), ent_identity, edge_identity, data.edge_index.data_ptr(), data.edge_attr.data_ptr()) + tuple(
             t.data_ptr() for t in tensors)
+        for layer in [self.conv1] + list(self.conv1_extra):
+            layer.derived_weights()                             # refreshed in place, outside the captured region
         hit = self._hip_graph
         if hit is None or hit[0] != key:
             side = torch.cuda.Stream(device=self.entity_embedding.device)
