@@ -255,6 +255,15 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
     else:
         roof = {'kernel': 'tile_kernel<BN_TANH> (%s)' % dom, 'bound': 'mfma', 'achieved': k['TFLOPs'],
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k['mfma_f32_frac'], 'traffic': None}
+    # HBM-side bytes of the same launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+    # MI355X_MICROARCH.md prescribes); collected offline with the profiler, committed under profiles/.
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
+            traffic = json.load(f)['kernels']
+        if args.shape == 'wn18rr' and dom in traffic:
+            roof['traffic'] = traffic[dom]['traffic_bytes']
+    except (OSError, KeyError, ValueError):
+        pass
     return {'roofline': roof, 'kernels': kern}
 
 
@@ -262,7 +271,8 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
     """Full filtered-MRR evaluation wall-clock: 2 x n_eval queries (tail + head side) in batches of 128 against all
     N entities. Three forms of the same computation, each timed on its second run:
       sharded_bits_s    dist.evaluate_sharded: encoder once (eval cache), filter bits built on the device, HIP
-                        score+filter+count kernel, entity table row-sharded over the ranks (RCCL exchange if W > 1);
+                        score+filter+count kernel per block of 128 queries, entity table row-sharded over the ranks
+                        (RCCL exchange if W > 1); sharded_bits_oneshot_s = the same with each rank's queries in ONE block;
       fused_dense_s     (rank 0 only) HIP kernel fed by dense [B, N] label blocks already resident on the device;
       reference_order_s (rank 0 only) what main.py:117-126 does: encoder per batch, [B, N] scores, double argsort."""
     N, R = shape['N'], shape['R']
@@ -282,14 +292,15 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
     filt = pkg.dist.FilterIndex.from_known(known, 2 * R).to(dev)
     out = {'queries': 2 * n_eval, 'batch': B, 'world': world}
     params.cache_encoder = True
-    for _ in range(2):
-        model._enc_cache = None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = pkg.dist.evaluate_sharded(model, graph, queries, filt, batch_size=B)
-        torch.cuda.synchronize()
-        out['sharded_bits_s'] = time.perf_counter() - t0
-    out['sharded_bits_mrr'] = res['mrr']
+    for name, bs in (('sharded_bits_s', B), ('sharded_bits_oneshot_s', None)):
+        for _ in range(2):
+            model._enc_cache = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = pkg.dist.evaluate_sharded(model, graph, queries, filt, batch_size=bs)
+            torch.cuda.synchronize()
+            out[name] = time.perf_counter() - t0
+        out[name.replace('_s', '_mrr')] = res['mrr']
     if rank == 0:
         batches = []
         for i in range(0, 2 * n_eval, B):

@@ -76,10 +76,15 @@ def sharded_rank_counts(x, qkey, obj, ent_shard, bias_shard, row0, filt, group=N
 
 
 @torch.no_grad()
-def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None):
+def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, trunk_chunk=2048):
     """Filtered MR / MRR / hits@{1,3,10} of `queries` ([Q, 3] int64: subject, relation id, object; both directions
     already expanded, as the loader's *_tail + *_head lists) with the entity table sharded over the group.
-    Rank r scores batches r, r + W, ...; the tail is padded so every rank runs the same number of collectives."""
+
+    Rank r owns the contiguous query range [c_r, c_{r+1}) (padded to a common length so every rank runs the same
+    collectives). The queries go to the device once, the ConvE trunk runs over them in chunks of `trunk_chunk`, and the
+    score + filter + count exchange runs per block of `batch_size` queries (None = all of a rank's queries in one
+    block: three launches and two collectives per rank in total). Ranks are accumulated on the device and reduced to
+    the metrics once at the end; the result does not depend on `batch_size`."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model.eval()
@@ -90,31 +95,34 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None):
     bias_shard = model.conv2.bias[b[rank]:b[rank + 1]].contiguous()
     dev = all_ent.device
     Q = queries.size(0)
-    nb = (Q + batch_size - 1) // batch_size
-    rounds = (nb + world - 1) // world
-    sums = torch.zeros(5, dtype=torch.float64, device=dev)     # count, mr, mrr, hits@1, hits@3 ... filled below
-    hits = torch.zeros(10, dtype=torch.float64, device=dev)
-    for it in range(rounds):
-        bi = it * world + rank
-        lo, hi = min(bi * batch_size, Q), min((bi + 1) * batch_size, Q)
-        real = hi - lo
-        q = queries[lo:hi].to(dev)
-        if real < batch_size:                                   # pad with a harmless query; its result is dropped
-            pad = torch.zeros((batch_size - real, 3), dtype=torch.int64, device=dev)
-            q = torch.cat([q, pad], dim=0)
-        sub, rel, obj = q[:, 0], q[:, 1], q[:, 2].contiguous()
-        x = model.conv2.trunk(all_ent.index_select(0, sub), all_rel.index_select(0, rel))
-        counts, _ = sharded_rank_counts(x, filt.query_keys(sub, rel), obj, ent_shard, bias_shard, b[rank], filt, group)
-        ranks = (1 + counts[:real, 0] + counts[:real, 1]).double()
-        sums[0] += real
-        sums[1] += ranks.sum()
-        sums[2] += (1.0 / ranks).sum()
-        hits += (ranks.view(-1, 1) <= torch.arange(1, 11, device=dev, dtype=torch.float64)).sum(0)
+    per = (Q + world - 1) // world
+    lo, hi = min(rank * per, Q), min((rank + 1) * per, Q)
+    real = hi - lo
+    q = torch.zeros((per, 3), dtype=torch.int64, device=dev)   # padding rows are harmless queries, dropped below
+    q[:real] = queries[lo:hi].to(dev)
+    sub, rel, obj = q[:, 0], q[:, 1], q[:, 2].contiguous()
+    x = torch.cat([model.conv2.trunk(all_ent.index_select(0, sub[i:i + trunk_chunk]),
+                                     all_rel.index_select(0, rel[i:i + trunk_chunk]))
+                   for i in range(0, per, trunk_chunk)], dim=0) if per > 0 else all_ent.new_zeros((0, all_ent.size(1)))
+    keys = filt.query_keys(sub, rel)
+    ranks = torch.zeros(per, dtype=torch.float64, device=dev)
+    step = per if not batch_size else int(batch_size)
+    for i in range(0, per, max(step, 1)):
+        counts, _ = sharded_rank_counts(x[i:i + step], keys[i:i + step], obj[i:i + step], ent_shard, bias_shard,
+                                        b[rank], filt, group)
+        ranks[i:i + step] = (1 + counts[:, 0] + counts[:, 1]).double()
+    ranks = ranks[:real]
+    sums = torch.zeros(13, dtype=torch.float64, device=dev)    # count, sum rank, sum 1/rank, hits@1..10
+    sums[0] = real
+    if real > 0:
+        sums[1] = ranks.sum()
+        sums[2] = (1.0 / ranks).sum()
+        sums[3:] = (ranks.view(-1, 1) <= torch.arange(1, 11, device=dev, dtype=torch.float64)).sum(0)
     if world > 1:
         dist.all_reduce(sums, group=group)
-        dist.all_reduce(hits, group=group)
-    count = float(sums[0])
-    res = {'count': count, 'mr': float(sums[1]) / count, 'mrr': float(sums[2]) / count}
+    sums = sums.tolist()
+    count = sums[0]
+    res = {'count': count, 'mr': sums[1] / count, 'mrr': sums[2] / count}
     for k in (1, 3, 10):
-        res['hits@%d' % k] = float(hits[k - 1]) / count
+        res['hits@%d' % k] = sums[2 + k] / count
     return res

@@ -325,3 +325,71 @@ def test_evaluate_sharded_two_ranks_one_gpu(pkg):
         assert got[r]['count'] == want['count']
         for k in ('mr', 'mrr', 'hits@1', 'hits@3', 'hits@10'):
             assert abs(got[r][k] - want[k]) < 1e-12, (r, k)
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_two_launch_path_matches_fused_and_golden(pkg, case, monkeypatch):
+    """The fused layer kernel is the default; the aggregate + dense two-launch path (used for shapes the fused kernel
+    does not take, and by the training forward) must give the same layer output."""
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index').to(DEV), g.t('dl_edge_attr').to(DEV)
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, sd['relation_embedding'].size(0), bias='conv1.bias' in sd)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    args = (sd['entity_embedding'].to(DEV), ei, ea[0], None, sd['edge_embeddings'].to(DEV), sd['relation_embedding'].to(DEV))
+    assert pkg._native.fused_supported(D, O)
+    with torch.no_grad():
+        fused_ent, fused_rel = conv(*args)
+        monkeypatch.setattr(pkg._native, 'fused_supported', lambda d_in, d_out: False)
+        conv._derived_stamp = None
+        two_ent, two_rel = conv(*args)
+    np.testing.assert_allclose(two_ent.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(two_ent.cpu().numpy(), fused_ent.cpu().numpy(), rtol=0, atol=2e-6)
+    assert torch.equal(two_rel, fused_rel)
+
+
+def test_layer_shapes_outside_the_fused_kernel(pkg, oracle):
+    """D not a multiple of 4 / O not a multiple of 4: scalar-lane aggregation + the generic (guarded-load) tile kernel."""
+    torch.manual_seed(3)
+    N, R, E, D, O = 97, 3, 400, 10, 18
+    tri = oracle.synthetic_triples(N, R, E, seed=5, zipf=1.0)
+    ei, ea = oracle.build_edge_list(tri, R)
+    ei, ea = torch.from_numpy(ei), torch.from_numpy(ea)
+    gen = torch.Generator().manual_seed(4)
+    sd = oracle.init_layer_state('conv1.', D, O, gen, bias=True)
+    x, ee, rel = torch.randn(N, D, generator=gen), torch.randn(2 * E, D, generator=gen), torch.randn(2 * R, D, generator=gen)
+    want_ent, want_rel = oracle.layer_forward(sd, 'conv1.', x, ei, ea[0], ee, rel)
+    conv = pkg.MGCNConv(D, O, 2 * R, bias=True)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items()})
+    conv.to(DEV).eval()
+    assert not pkg._native.fused_supported(D, O)
+    with torch.no_grad():
+        got_ent, got_rel = conv(x.to(DEV), ei.to(DEV), ea[0].to(DEV), None, ee.to(DEV), rel.to(DEV))
+    np.testing.assert_allclose(got_ent.cpu().numpy(), want_ent.numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got_rel.cpu().numpy(), want_rel.numpy(), rtol=0, atol=1e-5)
+
+
+def test_two_layer_stack_vs_composed_oracle(pkg, oracle):
+    """BASELINE.json's "2-layer" config has no reference counterpart: pinned by composing the oracle's layer."""
+    N, R, E, D, O = 500, 7, 2500, 20, 40
+    tri = oracle.synthetic_triples(N, R, E, seed=9, zipf=1.1)
+    ei, ea = oracle.build_edge_list(tri, R)
+    graph = pkg.Graph(edge_index=torch.from_numpy(ei), edge_attr=torch.from_numpy(ea))
+    graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
+    params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=5,
+                                   k_h=8, num_filter=4, kernel_size=3, bias=False, lbl_smooth=0.1, gcn_layers=2)
+    torch.manual_seed(11)
+    model = pkg.MGCN(N, R, E, params)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    graph.to(DEV)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        got_ent, got_rel = model.encode(graph)
+    e1, r1 = oracle.layer_forward(sd, 'conv1.', sd['entity_embedding'], torch.from_numpy(ei), torch.from_numpy(ea[0]),
+                                  sd['edge_embeddings'], sd['relation_embedding'])
+    e2, r2 = oracle.layer_forward(sd, 'conv1_extra.0.', e1, torch.from_numpy(ei), torch.from_numpy(ea[0]),
+                                  sd['edge_embeddings_extra.0'], r1)
+    np.testing.assert_allclose(got_ent.cpu().numpy(), e2.numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got_rel.cpu().numpy(), r2.numpy(), rtol=0, atol=2e-5)
