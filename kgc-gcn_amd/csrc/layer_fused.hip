@@ -65,191 +65,221 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float *__restrict__ w
 
 constexpr int FUSED_THREADS = 512;
 
+// PERSISTENT: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the gather -> multiply pipeline runs
+// straight across tile boundaries: stage s = 3*tile + mode; while the MFMA waves multiply stage s the gather waves
+// fetch stage s + 1 (the next tile's in-half when s is a self-loop stage). One workgroup barrier per stage. A
+// tile's epilogue values are staged in LDS during its last stage and stored (16 bytes per lane, whole rows) by the
+// MFMA waves at the beginning of the next one.
 template <int NT>
 __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs p) {
   constexpr int LDO = NT * 16 + 4;     // staging row stride (floats)
-  constexpr int NTW = (NT + 1) / 2;
+  constexpr int NTW = (NT + 3) / 4;    // column tiles per MFMA wave (at most)
   constexpr int U = 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lda = p.d + 2;
-  float *As = lds;                                        // [2][BM][lda]; reused as [BM][LDO] output staging
-  const int as_floats = (2 * BM * lda > BM * LDO) ? 2 * BM * lda : BM * LDO;
-  int *rps = reinterpret_cast<int *>(lds + as_floats);    // [2][BM + 1] slot positions of the tile's rows
+  float *As = lds;                     // [2][BM][lda]
+  float *Os = lds + 2 * BM * lda;      // [BM][LDO] epilogue staging (2*BM*lda*4 bytes is a multiple of 16)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool mfma_role = wave < 4;
-  const int r0 = int(blockIdx.x) * BM;
   const int nkb = (p.d + KS - 1) / KS;
-
-  if (tid < 2 * (BM + 1)) {
-    const int h = tid / (BM + 1), i = tid - h * (BM + 1);
-    const int node = (r0 + i < p.n) ? r0 + i : p.n;
-    rps[tid] = p.rowptr[int64_t(h) * (p.n + 1) + node];
-  }
-
-  // ---- MFMA-role state ----
-  const int rt = wave & 1, ch = (wave >> 1) & 1;
-  const int ct0 = ch * NTW;
-  const int nct = ch == 0 ? NTW : NT - NTW;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[NTW];
-  float4 wcur[NTW];
-  if (mfma_role) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int ct = (t < nct) ? ct0 + t : ct0;
-      wcur[t] = p.wp[int64_t(ct) * 64 + lane];   // (mode 0, kb 0): in flight across the first barrier
-    }
-  }
-  // ---- gather-role state ----
-  const int gtid = tid - 256;
-  const int gs = 1 << p.gs_log2;
-  const int grp = gtid >> p.gs_log2, lig = gtid & (gs - 1);
-  const int rpg = (BM * gs) / 256;                 // destinations per group (>= 1)
-  const int g_lo = grp * rpg, g_hi = g_lo + rpg;
-  const bool col_ok = lig * 4 < p.d;
-  const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
-
-  __syncthreads();
+  const int ntiles = (p.n + BM - 1) / BM;
+  const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);  // >= 1 (grid <= ntiles)
 
   // The two roles are two separate programs (disjoint live ranges -> each fits the register budget); both
-  // execute exactly four workgroup barriers, one per pipeline stage.
+  // execute exactly 3 * my_tiles + 1 workgroup barriers.
   if (!mfma_role) {
-    for (int mode = 0; mode < 3; ++mode) {
-      float *at = As + (mode & 1) * BM * lda;
-      if (p.ablate & 1) {
-      } else if (mode < 2) {
-        const int *rp = rps + mode * (BM + 1);
-        const int64_t base = int64_t(mode) * p.e;
-        int row = g_lo, nb = rp[g_lo + 1];
-        const int end = rp[g_hi];
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = rp[g_lo]; s < end; s += U) {
-          int4 r[U];
+    const int gtid = tid - 256;
+    const int gs = 1 << p.gs_log2;
+    const int grp = gtid >> p.gs_log2, lig = gtid & (gs - 1);
+    const int glane0 = lane & ~(gs - 1);             // first lane of this group inside its wave
+    const int rpg = (BM * gs) / 256;                 // destinations per group (>= 1, < gs)
+    const int g_lo = grp * rpg, g_hi = g_lo + rpg;
+    const bool col_ok = lig * 4 < p.d;
+    const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
+    int stage = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;
+      for (int mode = 0; mode < 3; ++mode, ++stage) {
+        float *at = As + (stage & 1) * BM * lda;
+        if (p.ablate & 1) {
+        } else if (mode < 2) {
+          // the group's rpg + 1 row pointers: lane i of the group holds the pointer of destination g_lo + i
+          int node = r0 + g_lo + (lig <= rpg ? lig : rpg);
+          node = node < p.n ? node : p.n;
+          const int myrp = p.rowptr[int64_t(mode) * (p.n + 1) + node];
+          const int64_t base = int64_t(mode) * p.e;
+          const int end = __shfl(myrp, glane0 + rpg);
+          int row = g_lo, nb = __shfl(myrp, glane0 + 1);
+          float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int s = __shfl(myrp, glane0); s < end; s += U) {
+            int4 r[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) r[u] = p.rec[base + ((s + u < end) ? s + u : end - 1)];
-          float4 xv[U], rv[U], ev[U];
+            for (int u = 0; u < U; ++u) r[u] = p.rec[base + ((s + u < end) ? s + u : end - 1)];
+            float4 xv[U], rv[U], ev[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) {
-            xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(r[u].x) * p.ldx + coff);
-            const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
-            rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
-            if (p.ee) {
-              const int64_t slot = base + ((s + u < end) ? s + u : end - 1);
-              ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d + coff);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (s + u < end) {
-              while (s + u >= nb) {  // group-uniform: the run of destination `row` is complete
-                if (col_ok) {
-                  float *dst = at + row * lda + lig * 4;
-                  *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
-                  *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
-                }
-                sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                ++row;
-                nb = rp[row + 1];
+            for (int u = 0; u < U; ++u) {
+              xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(r[u].x) * p.ldx + coff);
+              const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
+              rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
+              if (p.ee) {
+                const int64_t slot = base + ((s + u < end) ? s + u : end - 1);
+                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d + coff);
               }
-              float4 m = f4mul(xv[u], rv[u]);
-              if (p.ee) m = f4mul(m, ev[u]);
-              const float wgt = __int_as_float(r[u].z);
-              sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if (s + u < end) {
+                while (s + u >= nb) {  // group-uniform: the run of destination `row` is complete
+                  if (col_ok) {
+                    float *dst = at + row * lda + lig * 4;
+                    *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
+                    *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
+                  }
+                  sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                  ++row;
+                  nb = __shfl(myrp, glane0 + (row - g_lo) + 1);
+                }
+                float4 m = f4mul(xv[u], rv[u]);
+                if (p.ee) m = f4mul(m, ev[u]);
+                const float wgt = __int_as_float(r[u].z);
+                sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
+              }
+            }
+          }
+          for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
+            if (col_ok) {
+              float *dst = at + row * lda + lig * 4;
+              *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
+              *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
+            }
+            sum = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101
+          const float4 lr = *reinterpret_cast<const float4 *>(p.loop_rel + coff);
+          const float4 le = *reinterpret_cast<const float4 *>(p.loop_edge + coff);
+          for (int row = g_lo; row < g_hi; ++row) {
+            const int node = (r0 + row < p.n) ? r0 + row : p.n - 1;  // rows past N are computed and never stored
+            const float4 v = f4mul(f4mul(*reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff), lr), le);
+            if (col_ok) {
+              float *dst = at + row * lda + lig * 4;
+              *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
+              *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
             }
           }
         }
-        for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
-          if (col_ok) {
-            float *dst = at + row * lda + lig * 4;
-            *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
-          }
-          sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101
-        const float4 lr = *reinterpret_cast<const float4 *>(p.loop_rel + coff);
-        const float4 le = *reinterpret_cast<const float4 *>(p.loop_edge + coff);
-        for (int row = g_lo; row < g_hi; ++row) {
-          const int node = (r0 + row < p.n) ? r0 + row : p.n - 1;  // rows past N are computed and never stored
-          const float4 v = f4mul(f4mul(*reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff), lr), le);
-          if (col_ok) {
-            float *dst = at + row * lda + lig * 4;
-            *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
-          }
-        }
+        __syncthreads();  // end of stage: As[stage & 1] is complete
       }
-      __syncthreads();  // stage `mode` done: As[mode & 1] is complete
     }
-    __syncthreads();    // stage 3 (the MFMA waves multiply the last mode)
+    __syncthreads();      // the drain stage (the MFMA waves multiply the last mode)
   } else {
-    __syncthreads();    // stage 0 (the gather waves fetch the first mode)
-    for (int mode = 0; mode < 3; ++mode) {
-      const float *arow = As + (mode & 1) * BM * lda + (rt * 16 + fr) * lda + fq;
-      for (int kb = 0; kb < ((p.ablate & 2) ? 0 : nkb); ++kb) {
-        // next k-block's fragments (or the next mode's first block): one k-block ahead of the MFMAs
-        float4 wnext[NTW];
-        int nm = mode, nk = kb + 1;
-        if (nk == nkb) { nm = mode + 1; nk = 0; }
-        if (nm < 3) {
+    // MFMA wave w owns BOTH 16-row tiles of the block and a contiguous run of column tiles (4, 3, 3, 3 of the 13
+    // for O = 200): a weight fragment is loaded once per block (not once per row tile) and feeds two MFMAs, and
+    // only NTW fragments per k-block are needed, so they can be prefetched THREE k-blocks ahead in registers —
+    // the fragments come from L2 and one k-block of MFMAs (~0.4 us) does not cover that latency.
+    const int q4 = NT / 4, r4 = NT % 4;
+    const int wsel = wave;
+    const int ct0 = wsel * q4 + (wsel < r4 ? wsel : r4);
+    const int nct = q4 + (wsel < r4 ? 1 : 0);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int c4n = p.o >> 2;
+    const int nkb3 = 3 * nkb;                      // k-blocks per tile over the three modes
+    auto wload = [&](int g, int t) {               // fragment of k-block g (0 .. nkb3-1, mode-major), column tile t
+      const int ct = (t < nct) ? ct0 + t : ct0;
+      return p.wp[(int64_t(g) * NT + ct) * 64 + lane];
+    };
+    float4 w0[NTW], w1[NTW], w2[NTW];
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const int ct = (t < nct) ? ct0 + t : ct0;
-            wnext[t] = p.wp[(int64_t(nm * nkb + nk) * NT + ct) * 64 + lane];
-          }
+    for (int t = 0; t < NTW; ++t) {                // in flight across the first barrier
+      w0[t] = wload(0, t);
+      w1[t] = wload(1 % nkb3, t);
+      w2[t] = wload(2 % nkb3, t);
+    }
+    __syncthreads();      // stage 0 (the gather waves fetch the first mode of the first tile)
+    int stage = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;
+      if (it > 0 && !(p.ablate & 4)) {   // rows of the previous tile: staged during its last stage, visible since the barrier
+        const int pr0 = r0 - int(gridDim.x) * BM;
+        for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
+          const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
+          if (pr0 + lrow < p.n)
+            *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
         }
-        const int left = (p.d - kb * KS) >> 2;
-        const int nsteps = left < 4 ? left : 4;  // uniform: MFMA steps of 4 k in this block
-        float a[4];
+      }
+      f32x4 acc[2][NTW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = (i < nsteps) ? arow[kb * KS + 4 * i] : 0.f;
+      for (int t = 0; t < NTW; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      // one k-block: MFMAs on fragment set `wc`, which is then refilled with the k-block three ahead
+#define MGCN_KBLOCK(wc, G)                                                                                   \
+      {                                                                                                      \
+        const int g_ = (G);                                                                                  \
+        const int mode_ = g_ / nkb, kb_ = g_ - mode_ * nkb;                                                  \
+        const float *abase_ = As + ((stage + mode_) & 1) * BM * lda + fr * lda + fq + kb_ * KS;              \
+        const int left_ = (p.d - kb_ * KS) >> 2;                                                             \
+        const int nsteps_ = (p.ablate & 2) ? 0 : (left_ < 4 ? left_ : 4);                                    \
+        float a0_[4], a1_[4];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+          a0_[i] = (i < nsteps_) ? abase_[4 * i] : 0.f;                                                      \
+          a1_[i] = (i < nsteps_) ? abase_[16 * lda + 4 * i] : 0.f;                                           \
+        }                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+          if (i < nsteps_) {                                                                                 \
+            _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                \
+              const float bv_ = i == 0 ? wc[t].x : i == 1 ? wc[t].y : i == 2 ? wc[t].z : wc[t].w;           \
+              if (t < nct) {                                                                                 \
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[i], bv_, acc[0][t], 0, 0, 0);           \
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[i], bv_, acc[1][t], 0, 0, 0);           \
+              }                                                                                              \
+            }                                                                                                \
+          }                                                                                                  \
+        }                                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) wc[t] = wload((g_ + 3) % nkb3, t);                   \
+        if (kb_ == nkb - 1) {                                                                                \
+          if (mode_ == 2 && !(p.ablate & 8)) epilogue_to_staging();                                          \
+          __syncthreads(); /* end of stage */                                                                \
+        }                                                                                                    \
+      }
+
+      auto epilogue_to_staging = [&]() {  // /3, bias, BN(eval), tanh; lane holds rows rt*16+fq*4+j, column (ct0+t)*16+fr
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < nsteps) {
+        for (int t = 0; t < NTW; ++t) {
+          const int col = (ct0 + t) * 16 + fr;
+          if (t >= nct || col >= p.o) continue;
+          const float cb = p.bias ? p.bias[col] : 0.f;
+          const float mean = p.bn_mean[col];
+          const float inv = 1.0f / sqrtf(p.bn_var[col] + p.bn_eps);
+          const float gam = p.bn_gamma[col], bet = p.bn_beta[col];
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-              const float bv = i == 0 ? wcur[t].x : i == 1 ? wcur[t].y : i == 2 ? wcur[t].z : wcur[t].w;
-              if (t < nct) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv, acc[t], 0, 0, 0);
+          for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = acc[rt][t][j] / 3.0f;
+              if (p.bias) v = v + cb;
+              Os[(rt * 16 + fq * 4 + j) * LDO + col] = tanhf_((v - mean) * inv * gam + bet);
             }
           }
         }
-        if (nm < 3) {
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) wcur[t] = wnext[t];
-        }
-      }
-      __syncthreads();  // stage mode+1 done
-    }
-  }
+      };
 
-  // ---------------- epilogue: /3, bias, BN(eval), tanh; staged through LDS, 16-byte row stores ----------------
-  float *os = As;
-  if (mfma_role) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = (ct0 + t) * 16 + fr;
-      if (t >= nct || col >= p.o) continue;
-      const float cb = p.bias ? p.bias[col] : 0.f;
-      const float mean = p.bn_mean[col];
-      const float inv = 1.0f / sqrtf(p.bn_var[col] + p.bn_eps);
-      const float gam = p.bn_gamma[col], bet = p.bn_beta[col];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = acc[t][j] / 3.0f;
-        if (p.bias) v = v + cb;
-        os[(rt * 16 + fq * 4 + j) * LDO + col] = tanhf_((v - mean) * inv * gam + bet);
+      for (int g0 = 0; g0 < nkb3; g0 += 3) {   // nkb3 is a multiple of 3: fragment sets rotate w0 -> w1 -> w2
+        MGCN_KBLOCK(w0, g0)
+        MGCN_KBLOCK(w1, g0 + 1)
+        MGCN_KBLOCK(w2, g0 + 2)
+      }
+#undef MGCN_KBLOCK
+      stage += 3;
+    }
+    if (!(p.ablate & 4)) {                     // rows of the last tile
+      const int pr0 = (int(blockIdx.x) + (my_tiles - 1) * int(gridDim.x)) * BM;
+      for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
+        const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
+        if (pr0 + lrow < p.n)
+          *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
       }
     }
-  }
-  __syncthreads();
-  const int c4n = p.o >> 2;
-  for (int s4 = tid; s4 < BM * c4n; s4 += FUSED_THREADS) {
-    const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-    if (r0 + lrow < p.n)
-      *reinterpret_cast<float4 *>(p.out + int64_t(r0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(os + lrow * LDO + lc);
   }
 }
 
@@ -309,10 +339,12 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   int gl = 3;  // lanes per gather group: smallest power of two >= D/4, at least 8 (so 32 rows cover <= 32 groups)
   while ((1 << gl) * 4 < dim_in) ++gl;
   p.gs_log2 = gl;
-  const unsigned grid = unsigned((num_nodes + BM - 1) / BM);
+  const int ntiles = int((num_nodes + BM - 1) / BM);
   const int lda = dim_in + 2, ldo_s = nt * 16 + 4;
-  const size_t as_floats = size_t(2) * BM * lda > size_t(BM) * ldo_s ? size_t(2) * BM * lda : size_t(BM) * ldo_s;
-  const size_t lds_bytes = as_floats * 4 + 2 * (BM + 1) * 4;
+  const size_t lds_bytes = (size_t(2) * BM * lda + size_t(BM) * ldo_s) * 4;
+  int grid_i = 2 * 256;   // persistent: two 8-wave blocks per CU (128 VGPRs, <= 80 KiB LDS each)
+  if (const char *g = getenv("MGCN_FUSED_GRID")) grid_i = atoi(g);
+  const unsigned grid = unsigned(grid_i < ntiles ? grid_i : ntiles);
   switch (nt) {
     case 2: hipLaunchKernelGGL((layer_fused_kernel<2>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
     case 4: hipLaunchKernelGGL((layer_fused_kernel<4>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
