@@ -393,3 +393,26 @@ def test_two_layer_stack_vs_composed_oracle(pkg, oracle):
                                   sd['edge_embeddings_extra.0'], r1)
     np.testing.assert_allclose(got_ent.cpu().numpy(), e2.numpy(), rtol=0, atol=5e-5)
     np.testing.assert_allclose(got_rel.cpu().numpy(), r2.numpy(), rtol=0, atol=2e-5)
+
+
+def test_integration_stub(pkg):
+    """The ctypes stub printed in INTEGRATION.md §2 is executed verbatim and must reproduce MGCNConv's eval output."""
+    import re
+    text = open(os.path.join(os.path.dirname(GOLDEN), '..', 'INTEGRATION.md')).read()
+    block = re.search(r"## 2\. Operator level.*?```python\n(.*?)```", text, re.S).group(1)
+    block = block.replace("'kgc-gcn_amd/csrc/libmgcn_hip.so'", repr(pkg._native.LIB_PATH))
+    ns = {}
+    exec(block, ns)
+    g = golden('syn_b')
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, sd['relation_embedding'].size(0))
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    N = sd['entity_embedding'].size(0)
+    rowptr, rec, perm = ns['build_csr'](ei, ea[0].contiguous(), N, sd['relation_embedding'].size(0) + 1)
+    with torch.no_grad():
+        out = ns['layer_eval'](conv, sd['entity_embedding'].to(DEV), rowptr, rec, perm, sd['edge_embeddings'].to(DEV),
+                               sd['relation_embedding'].to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
