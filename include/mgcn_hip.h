@@ -135,14 +135,20 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * fragment order: wp_dev = mgcn_pack_weights() of the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes
  * bytes, 16-byte aligned; re-pack whenever a weight changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all
  * operands are 16-byte aligned, dim_in % 4 == 0, dim_in <= 256, dim_out % 4 == 0 and dim_out <= 208 — callers then
- * use (2) followed by (4). */
+ * use (2) followed by (4).
+ * Destination partition: only destinations [node_begin, node_end) are computed; out_dev holds THOSE rows
+ * (row 0 = node_begin). A rank may hold only its shard of the slot-ordered per-edge table — the rows of the in-half
+ * slots [rowptr_in[node_begin], rowptr_in[node_end]) followed by those of the out-half slots of the same nodes — and
+ * passes ee_sub_in / ee_sub_out such that the row of global slot s (out-half slots numbered from num_edges_half) is
+ * s - ee_sub_{half}; with the whole table both are 0. x_dev is always the whole [N, D] layer input. */
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
                          const float *ee_dev, int32_t ee_in_slot_order, const float *loop_edge_dev,
                          const float *wp_dev, const float *bias_dev, const float *bn_mean_dev,
                          const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
-                         float bn_eps, float *out_dev, int64_t ldo, void *stream);
+                         float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
+                         int64_t ee_sub_in, int64_t ee_sub_out, void *stream);
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 

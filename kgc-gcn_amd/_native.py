@@ -28,7 +28,8 @@ _SIGNATURES = {
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
-                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _ptr]),
+                                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
+                                            _i64, _i64, _ptr]),
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
@@ -225,22 +226,33 @@ def pack_weights(w_cat, out=None):
 
 
 def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
-                    bn_gamma, bn_beta, eps, out):
+                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0)):
     """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
-    `w_packed` = pack_weights(stacked [3D, O] weights)."""
+    `w_packed` = pack_weights(stacked [3D, O] weights). With `node_range` = (n0, n1) only those destinations are
+    computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
+    graph.GraphCSR.edge_table_shard) with `ee_sub` its two slot offsets."""
     N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), int(d_out)
+    n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
+    if not 0 <= n0 <= n1 <= N:
+        raise NativeError('layer_fwd_fused: node range (%d, %d) outside [0, %d]' % (n0, n1, N))
+    sharded = tuple(ee_sub) != (0, 0) or (ee is not None and ee.size(0) != 2 * E)
     _same_device(csr.rowptr, x, rel, loop_rel, ee, loop_edge, w_packed, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
     if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows - 1, D) or loop_rel.numel() != D or loop_edge.numel() != D:
         raise NativeError('layer_fwd_fused: x / rel / loop rows do not match the graph')
-    if ee is not None and (tuple(ee.shape) != (2 * E, D) or not ee.is_contiguous()):
+    if ee is not None and not sharded and (tuple(ee.shape) != (2 * E, D) or not ee.is_contiguous()):
         raise NativeError('layer_fwd_fused: per-edge table must be contiguous (%d, %d)' % (2 * E, D))
+    if ee is not None and sharded:
+        rows = csr.shard_slot_counts(n0, n1)
+        if not ee_in_slot_order or tuple(ee.shape) != (rows[0] + rows[1], D) or not ee.is_contiguous() or \
+                tuple(int(v) for v in ee_sub) != csr.shard_ee_sub(n0, n1):
+            raise NativeError('layer_fwd_fused: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
     if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
         raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:
             raise NativeError('layer_fwd_fused: per-column vectors must have %d elements' % O)
-    if tuple(out.shape) != (N, O):
-        raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (N, O))
+    if tuple(out.shape) != (n1 - n0, O):
+        raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (n1 - n0, O))
     _check(lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
@@ -248,7 +260,8 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(w_packed, torch.float32, 'w_packed'), _dev(bias, torch.float32, 'bias', True),
         _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
         _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
-        _dev(out, torch.float32, 'out'), _ld(out), _stream(x)), 'mgcn_layer_fwd_fused')
+        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), _stream(x)),
+        'mgcn_layer_fwd_fused')
     return out
 
 

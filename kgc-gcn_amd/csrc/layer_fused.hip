@@ -41,6 +41,8 @@ struct FusedArgs {
   float *out;
   int64_t ldx, ldo;
   int32_t n, e, d, o, rel_rows, ee_slot_order, gs_log2;
+  int32_t node0, node1;   // destinations [node0, node1) are this launch's (this rank's) share; out row 0 = node0
+  int64_t ee_sub[2];      // slot-order per-edge table shard: row of global slot s of half h = s - ee_sub[h]
   int32_t ablate;  // timing diagnostics only (MGCN_FUSED_ABLATE): bit 0 skips the gather, bit 1 the MFMA loop
   float bn_eps;
 };
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool mfma_role = wave < 4;
   const int nkb = (p.d + KS - 1) / KS;
-  const int ntiles = (p.n + BM - 1) / BM;
+  const int ntiles = (p.node1 - p.node0 + BM - 1) / BM;
   const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);  // >= 1 (grid <= ntiles)
 
   // The two roles are two separate programs (disjoint live ranges -> each fits the register budget); both
@@ -100,14 +102,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
     int stage = 0;
     for (int it = 0; it < my_tiles; ++it) {
-      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;
+      const int r0 = p.node0 + (int(blockIdx.x) + it * int(gridDim.x)) * BM;
       for (int mode = 0; mode < 3; ++mode, ++stage) {
         float *at = As + (stage & 1) * BM * lda;
         if (p.ablate & 1) {
         } else if (mode < 2) {
           // the group's rpg + 1 row pointers: lane i of the group holds the pointer of destination g_lo + i
           int node = r0 + g_lo + (lig <= rpg ? lig : rpg);
-          node = node < p.n ? node : p.n;
+          node = node < p.node1 ? node : p.node1;
           const int myrp = p.rowptr[int64_t(mode) * (p.n + 1) + node];
           const int64_t base = int64_t(mode) * p.e;
           const int end = __shfl(myrp, glane0 + rpg);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
               rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
               if (p.ee) {
                 const int64_t slot = base + ((s + u < end) ? s + u : end - 1);
-                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d + coff);
+                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot - p.ee_sub[mode] : int64_t(r[u].w)) * p.d + coff);
               }
             }
 #pragma unroll
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
           const float4 lr = *reinterpret_cast<const float4 *>(p.loop_rel + coff);
           const float4 le = *reinterpret_cast<const float4 *>(p.loop_edge + coff);
           for (int row = g_lo; row < g_hi; ++row) {
-            const int node = (r0 + row < p.n) ? r0 + row : p.n - 1;  // rows past N are computed and never stored
+            const int node = (r0 + row < p.node1) ? r0 + row : p.node1 - 1;  // rows past the range are computed, never stored
             const float4 v = f4mul(f4mul(*reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff), lr), le);
             if (col_ok) {
               float *dst = at + row * lda + lig * 4;
@@ -199,12 +201,12 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     __syncthreads();      // stage 0 (the gather waves fetch the first mode of the first tile)
     int stage = 0;
     for (int it = 0; it < my_tiles; ++it) {
-      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;
+      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;   // local row (node - node0) of the tile
       if (it > 0 && !(p.ablate & 4)) {   // rows of the previous tile: staged during its last stage, visible since the barrier
         const int pr0 = r0 - int(gridDim.x) * BM;
         for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
           const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-          if (pr0 + lrow < p.n)
+          if (pr0 + lrow < p.node1 - p.node0)
             *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
         }
       }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
       const int pr0 = (int(blockIdx.x) + (my_tiles - 1) * int(gridDim.x)) * BM;
       for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
         const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-        if (pr0 + lrow < p.n)
+        if (pr0 + lrow < p.node1 - p.node0)
           *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
       }
     }
@@ -309,9 +311,11 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                     const float *ee_dev, int32_t ee_in_slot_order, const float *loop_edge_dev,
                                     const float *wp_dev, const float *bias_dev, const float *bn_mean_dev,
                                     const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
-                                    float bn_eps, float *out_dev, int64_t ldo, void *stream) {
+                                    float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
+                                    int64_t ee_sub_in, int64_t ee_sub_out, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
                "layer_fwd_fused: bad sizes");
+  MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "layer_fwd_fused: bad node range");
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 64 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "layer_fwd_fused: sizes exceed int32");
   MGCN_REQUIRE(rowptr_dev && x_dev && loop_rel_dev && loop_edge_dev && wp_dev && bn_mean_dev && bn_var_dev &&
@@ -324,10 +328,11 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   if (!aligned || dim_in % 4 != 0 || dim_in > 256 || dim_out % 4 != 0 || dim_out > 208)
     return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, D %% 4 == 0, D <= 256, "
                       "O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
-  if (num_nodes == 0) return MGCN_OK;
+  if (node_end == node_begin) return MGCN_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nt = pick_nt(dim_out);
   FusedArgs p = {};
+  p.node0 = int32_t(node_begin); p.node1 = int32_t(node_end); p.ee_sub[0] = ee_sub_in; p.ee_sub[1] = ee_sub_out;
   p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;
   p.wp = reinterpret_cast<const float4 *>(wp_dev);
@@ -339,7 +344,7 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   int gl = 3;  // lanes per gather group: smallest power of two >= D/4, at least 8 (so 32 rows cover <= 32 groups)
   while ((1 << gl) * 4 < dim_in) ++gl;
   p.gs_log2 = gl;
-  const int ntiles = int((num_nodes + BM - 1) / BM);
+  const int ntiles = int((node_end - node_begin + BM - 1) / BM);
   const int lda = dim_in + 2, ldo_s = nt * 16 + 4;
   const size_t lds_bytes = (size_t(2) * BM * lda + size_t(BM) * ldo_s) * 4;
   int grid_i = 2 * 256;   // persistent: two 8-wave blocks per CU (128 VGPRs, <= 80 KiB LDS each)

@@ -17,8 +17,10 @@ from . import _native
 
 
 def shard_bounds(n, world):
-    """Contiguous, balanced row ranges: rank r owns [b[r], b[r+1])."""
-    return [(n * r) // world for r in range(world + 1)]
+    """Contiguous row ranges of equal length ceil(n / world) (the last ones shorter or empty): rank r owns
+    [b[r], b[r+1]). Equal chunks let a layer output be exchanged with one all-gather."""
+    chunk = (n + world - 1) // world
+    return [min(r * chunk, n) for r in range(world + 1)]
 
 
 class FilterIndex(object):
@@ -76,7 +78,47 @@ def sharded_rank_counts(x, qkey, obj, ent_shard, bias_shard, row0, filt, group=N
 
 
 @torch.no_grad()
-def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, trunk_chunk=2048):
+def encode_sharded(model, graph, group=None):
+    """Destination-partitioned encoder: rank r computes rows [b_r, b_{r+1}) of every layer's output with
+    the fused layer kernel, reading only ITS shard of the slot-ordered per-edge tables (1/W of their bytes — the
+    table is what does not fit one GPU at 10^8 triples); every destination's sum is formed wholly on one rank, so the
+    rows are bit-identical to the single-GPU ones. Sources are arbitrary, so each layer output is all-gathered (RCCL)
+    before the next layer / the scorer reads it. Returns (all_ent [N, O], all_rel [2R, O]) complete on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    model.eval()
+    edge_type, edge_ids = graph.edge_attr
+    ent_identity, edge_identity = model._graph_facts(graph)
+    layers = [model.conv1] + list(model.conv1_extra)
+    if world == 1 or not (ent_identity and edge_identity) or not all(
+            _native.fused_supported(l.in_channels, l.out_channels) for l in layers):
+        return model.encode(graph)                              # shapes outside the fused kernel: replicated encoder
+    csr = graph.csr(model.relation_embedding.size(0) + 1)
+    model._use_slot_order(csr)
+    N = csr.num_nodes
+    b = shard_bounds(N, world)
+    n0, n1, chunk = b[rank], b[rank + 1], (N + world - 1) // world
+    x, rel = model.entity_embedding.detach(), model.relation_embedding.detach()
+    tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
+    ee_sub = csr.shard_ee_sub(n0, n1)
+    for layer, table in zip(layers, tables):
+        _, wpack = layer.derived_weights()
+        shard = csr.edge_table_shard(table.detach(), n0, n1)   # a deployment at scale keeps ONLY this on the rank
+        local = torch.zeros((chunk, layer.out_channels), dtype=torch.float32, device=x.device)
+        bn = layer.ent_bn
+        _native.layer_fwd_fused(csr, x.contiguous(), rel.contiguous(), layer.loop_rel.reshape(-1), shard, True,
+                                layer.loop_edge.reshape(-1), wpack, layer.out_channels, layer.bias, bn.running_mean,
+                                bn.running_var, bn.weight, bn.bias, bn.eps, local[:n1 - n0], node_range=(n0, n1),
+                                ee_sub=ee_sub)
+        full = torch.empty((world * chunk, layer.out_channels), dtype=torch.float32, device=x.device)
+        dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal row chunks, gathered in place
+        x = full[:N]
+        rel = _native.matmul(rel.contiguous(), layer.rels_weight)
+    return x, rel
+
+
+@torch.no_grad()
+def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, trunk_chunk=2048, shard_encoder=False):
     """Filtered MR / MRR / hits@{1,3,10} of `queries` ([Q, 3] int64: subject, relation id, object; both directions
     already expanded, as the loader's *_tail + *_head lists) with the entity table sharded over the group.
 
@@ -84,11 +126,13 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
     collectives). The queries go to the device once, the ConvE trunk runs over them in chunks of `trunk_chunk`, and the
     score + filter + count exchange runs per block of `batch_size` queries (None = all of a rank's queries in one
     block: three launches and two collectives per rank in total). Ranks are accumulated on the device and reduced to
-    the metrics once at the end; the result does not depend on `batch_size`."""
+    the metrics once at the end; the result does not depend on `batch_size`. `shard_encoder=True` also partitions the
+    encoder by destination (encode_sharded)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model.eval()
-    all_ent, all_rel = model.encode(graph)                     # replicated encoder; this rank keeps its row shard
+    # encoder: replicated (default; 12-33 MB of output at FB15k-237 / WN18RR) or destination-partitioned
+    all_ent, all_rel = encode_sharded(model, graph, group) if shard_encoder else model.encode(graph)
     N = all_ent.size(0)
     b = shard_bounds(N, world)
     ent_shard = all_ent[b[rank]:b[rank + 1]].contiguous()

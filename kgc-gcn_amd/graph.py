@@ -46,6 +46,31 @@ class GraphCSR(object):
             self._inv_perm = inv
         return self._inv_perm
 
+    # -- destination partition ------------------------------------------------------
+    def _shard_bounds(self, n0, n1):
+        key = (int(n0), int(n1))
+        cache = self.__dict__.setdefault('_shard_cache', {})
+        if key not in cache:
+            rp = self.rowptr[:, [key[0], key[1]]].cpu().tolist()      # [[in0, in1], [out0, out1]] slot positions
+            cache[key] = ((rp[0][0], rp[0][1]), (rp[1][0], rp[1][1]))
+        return cache[key]
+
+    def shard_slot_counts(self, n0, n1):
+        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
+        return i1 - i0, o1 - o0
+
+    def shard_ee_sub(self, n0, n1):
+        """(ee_sub_in, ee_sub_out) for a table that holds only the slots of destinations [n0, n1)."""
+        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
+        return i0, self.num_edges_half + o0 - (i1 - i0)
+
+    def edge_table_shard(self, table_slot_order, n0, n1):
+        """Rows of a slot-ordered per-edge table that destinations [n0, n1) need: their in-half slots, then their
+        out-half slots (each a contiguous run). 1/W of the table per rank for a balanced partition."""
+        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
+        e = self.num_edges_half
+        return torch.cat([table_slot_order[i0:i1], table_slot_order[e + o0:e + o1]], dim=0).contiguous()
+
     def norms(self):
         """Per-slot degree norm (f32 view of the record's third word)."""
         return self.rec[:, 2].contiguous().view(torch.float32)

@@ -99,7 +99,8 @@ def test_sharded_counts_equal_unsharded_gloo():
 
 
 def test_shard_bounds_and_filter_index(pkg):
-    assert pkg.dist.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert pkg.dist.shard_bounds(10, 4) == [0, 3, 6, 9, 10]
+    assert pkg.dist.shard_bounds(3, 4) == [0, 1, 2, 3, 3]
     assert pkg.dist.shard_bounds(14541, 8)[-1] == 14541
     f = pkg.dist.FilterIndex.from_known({(3, 1): [5, 2], (0, 0): [7]}, 4)
     assert f.keys.tolist() == [0, 13] and f.ptr.tolist() == [0, 1, 3] and f.tails.tolist() == [7, 2, 5]

@@ -288,6 +288,14 @@ def test_evaluate_sharded_world1_vs_golden(pkg, case):
 
 
 def _sharded_worker(rank, world, port, case, q):
+    try:
+        _sharded_worker_body(rank, world, port, case, q)
+    except Exception:                                        # surface the failure in the parent instead of a timeout
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+
+
+def _sharded_worker_body(rank, world, port, case, q):
     import importlib
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -299,6 +307,15 @@ def _sharded_worker(rank, world, port, case, q):
     model, dl, params = _model(pkg, g)
     filt = dl.filter_index().to(DEV)
     res = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries('test'), filt, batch_size=7)
+    res2 = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries('test'), filt, batch_size=None, shard_encoder=True)
+    ent_sharded, rel_sharded = pkg.dist.encode_sharded(model, dl.graph)
+    model._enc_cache = None
+    with torch.no_grad():                                    # frozen path = the fused kernel, like the sharded encoder
+        ent_single, rel_single = model.encode(dl.graph)
+    res['encoder_rows_bit_identical'] = bool(torch.equal(ent_sharded, ent_single) and torch.equal(rel_sharded, rel_single))
+    res['debug'] = (tuple(ent_sharded.shape), tuple(ent_single.shape), float((ent_sharded - ent_single).abs().max()),
+                    float((rel_sharded - rel_single).abs().max()), {k: (res[k], res2[k]) for k in ('mr', 'mrr')})
+    res['sharded_encoder_metrics_equal'] = all(abs(res[k] - res2[k]) < 1e-12 for k in ('mr', 'mrr', 'hits@1', 'hits@10'))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -314,7 +331,7 @@ def test_evaluate_sharded_two_ranks_one_gpu(pkg):
     procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(world))
+    got = dict(q.get(timeout=120) for _ in range(world))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -322,6 +339,8 @@ def test_evaluate_sharded_two_ranks_one_gpu(pkg):
     model, dl, params = _model(pkg, g)
     want = pkg.dist.evaluate_sharded(model, dl.graph, dl.eval_queries('test'), dl.filter_index().to(DEV), batch_size=7)
     for r in range(world):
+        assert 'error' not in got[r], got[r]['error']
+        assert got[r]['encoder_rows_bit_identical'] and got[r]['sharded_encoder_metrics_equal'], got[r]['debug']
         assert got[r]['count'] == want['count']
         for k in ('mr', 'mrr', 'hits@1', 'hits@3', 'hits@10'):
             assert abs(got[r][k] - want[k]) < 1e-12, (r, k)
@@ -416,3 +435,38 @@ def test_integration_stub(pkg):
         out = ns['layer_eval'](conv, sd['entity_embedding'].to(DEV), rowptr, rec, perm, sd['edge_embeddings'].to(DEV),
                                sd['relation_embedding'].to(DEV))
     np.testing.assert_allclose(out.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_destination_ranges_with_table_shards(pkg, case):
+    """One process plays three ranks in turn: each computes its destination range from its shard of the per-edge table
+    (fused kernel, node_range + ee_sub); the concatenation is bit-identical to the full launch."""
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    N, R = int(g['dl_num_entity']), int(g['dl_num_relation'])
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, 2 * R, bias='conv1.bias' in sd)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV)
+    x, rel = sd['entity_embedding'].to(DEV), sd['relation_embedding'].to(DEV)
+    table = sd['edge_embeddings'].to(DEV).index_select(0, csr.perm)
+    _, wpack = conv.derived_weights()
+    bn = conv.ent_bn
+    nat = pkg._native
+
+    def run(n0, n1, ee, ee_sub):
+        out = torch.empty((n1 - n0, O), device=DEV)
+        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), ee, True, conv.loop_edge.reshape(-1), wpack, O,
+                            conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                            node_range=(n0, n1), ee_sub=ee_sub)
+        return out
+    full = run(0, N, table, (0, 0))
+    np.testing.assert_allclose(full.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
+    b = pkg.dist.shard_bounds(N, 3)
+    parts = [run(b[r], b[r + 1], csr.edge_table_shard(table, b[r], b[r + 1]), csr.shard_ee_sub(b[r], b[r + 1]))
+             for r in range(3)]
+    assert torch.equal(torch.cat(parts, dim=0), full)
+    with pytest.raises(nat.NativeError):                       # a shard that does not belong to the range is refused
+        run(b[0], b[1], csr.edge_table_shard(table, b[1], b[2]), csr.shard_ee_sub(b[1], b[2]))
