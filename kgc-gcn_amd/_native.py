@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')
+LIB_PATH = os.environ.get('MGCN_LIB') or os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')   # MGCN_LIB: A/B builds
 ABI_VERSION = 1
 
 _lib = None
