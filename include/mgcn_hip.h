@@ -54,23 +54,33 @@ const char *mgcn_last_error(void);
  * norms per half, `compute_norm` model.py:72-80, hoisted out of the step because the graph is
  * static).
  *   edge_index_host [2, 2E] int64 (row 0 = src, row 1 = dst), edge_type_host [2E] int64.
+ * Slot layout produced: [in-half segments by destination | out-half segments by destination | hub segments],
+ * every segment in edge-id order (the order a CPU scatter-add visits the edges). A destination with more than
+ * hub_threshold slots in a half is a HUB (hub_threshold <= 0: no hubs): its segment moves to the hub region and is
+ * cut into chunks of hub_chunk slots, so that no lane group ever walks a long list alone (degree skew);
+ * the kernels sum each chunk separately and combine a hub's chunk sums in a fixed order (a strided partition over
+ * the lane groups of one workgroup, then the group sums in group order) — still no atomics, still reproducible.
  * Outputs (host, caller-allocated):
- *   rowptr_host [2, N+1] int32   per half, CSR by DESTINATION, positions relative to the half;
- *   rec_host    [2E]             slot h*E + p = p-th edge of half h in (dst, edge id) order — the
- *                                order a CPU scatter-add visits them;
- *   perm_host   [2E] int64       slot -> reference edge id (to lay the per-edge table out in slot
- *                                order once, so the kernel streams it);
- * Optional outputs for the backward pass (all three NULL, or all three non-NULL plus the type pair):
- *   slot_dst_host [2E] int32     destination node of each slot;
+ *   rowptr_host [2, N+1] int32   ABSOLUTE slot positions of the non-hub segments (a hub's segment there is empty);
+ *   rec_host    [2E]             one record per slot;
+ *   perm_host   [2E] int64       slot -> reference edge id (to lay the per-edge table out in slot order once);
+ *   hubinfo_host [2, N, 2] int32 (first chunk, chunk count) of destination n in half h, (-1, 0) if not a hub;
+ *   chunks_host [max_chunks, 4] int32  {begin, end, first chunk of its hub, chunk count of its hub}: absolute slot
+ *                                range [begin, end) of every chunk; *num_chunks_host = chunks in use
+ *                                (the three may be NULL when hub_threshold <= 0).
+ * Optional outputs for the backward pass (all NULL or all non-NULL):
+ *   slot_dst_host [2E] int32     destination node of each slot, bit 31 = half;
  *   srcptr_host [2, N+1] int32, srcslots_host [2E] int32
- *                                per half, the slots (global slot ids, ascending) grouped by SOURCE;
+ *                                per half, the slots (ascending) grouped by SOURCE; srcptr indexes srcslots;
  *   typeptr_host [num_rel_rows+1] int32, typeslots_host [2E] int32
  *                                all slots (ascending) grouped by relation-table row.
  * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows).
  */
 int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_rel_rows,
                         const int64_t *edge_index_host, const int64_t *edge_type_host,
-                        int32_t *rowptr_host, mgcn_edge_rec *rec_host, int64_t *perm_host,
+                        int64_t hub_threshold, int64_t hub_chunk, int32_t *rowptr_host,
+                        mgcn_edge_rec *rec_host, int64_t *perm_host, int32_t *hubinfo_host,
+                        int32_t *chunks_host, int64_t max_chunks, int64_t *num_chunks_host,
                         int32_t *slot_dst_host, int32_t *srcptr_host, int32_t *srcslots_host,
                         int32_t *typeptr_host, int32_t *typeslots_host);
 
@@ -91,12 +101,18 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
  *   (then the third block is not written and A needs only 2D columns), a_dev [N, lda].
  * Only destinations [node_begin, node_end) are processed (rows of a_dev indexed by global node id): row chunks
  * can be pipelined against (4) on another stream, and a destination partition is one rank's share.
+ * Hubs: [chunk_begin, chunk_end) are the chunks of the hubs among [node_begin, node_end) — one run, because the hub
+ * region is in node order (all chunks for the whole graph). When it is not empty (hubinfo_dev / chunks_dev from the
+ * feeder) the chunk sums are first written to partial_dev [chunk_end - chunk_begin, D] by a pre-pass launch on the
+ * same stream, a second launch folds every hub's chunk sums into the row of its first chunk, and the main launch
+ * adds that one row per hub.
  */
 int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                        const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                        int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
                        int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
-                       int64_t node_begin, int64_t node_end, void *stream);
+                       int64_t node_begin, int64_t node_end, const int32_t *hubinfo_dev, const int32_t *chunks_dev,
+                       int64_t chunk_begin, int64_t chunk_end, float *partial_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) Aggregation backward (autograd through (2); driven by main.py:66). Given g = dL/dA [N, lda]
@@ -110,7 +126,7 @@ int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, i
  * Any of gx/gee/grel may be NULL. gx [N, D], gee [2E, D] in slot order, grel [num_rel_rows, D].
  */
 int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
-                       const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev, const int32_t *srcptr_dev,
+                       const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev /* bit 31 = half */, const int32_t *srcptr_dev,
                        const int32_t *srcslots_dev, const int32_t *typeptr_dev, const int32_t *typeslots_dev,
                        const float *x_dev, int64_t ldx, const float *rel_dev, const float *ee_dev,
                        const float *g_dev, int64_t ldg, float *gx_dev, float *gee_dev, float *grel_dev,
@@ -139,8 +155,10 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * Destination partition: only destinations [node_begin, node_end) are computed; out_dev holds THOSE rows
  * (row 0 = node_begin). A rank may hold only its shard of the slot-ordered per-edge table — the rows of the in-half
  * slots [rowptr_in[node_begin], rowptr_in[node_end]) followed by those of the out-half slots of the same nodes — and
- * passes ee_sub_in / ee_sub_out such that the row of global slot s (out-half slots numbered from num_edges_half) is
- * s - ee_sub_{half}; with the whole table both are 0. x_dev is always the whole [N, D] layer input. */
+ * then the hub slots [chunks[chunk_begin].begin, chunks[chunk_end - 1].end) of the same nodes — and passes
+ * ee_sub_in / ee_sub_out / ee_sub_hub such that the row of (absolute) slot s is s - ee_sub_{region}; with the whole
+ * table all three are 0. x_dev is always the whole [N, D] layer input.
+ * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [chunk_end - chunk_begin, dim_in]. */
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
@@ -148,7 +166,9 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
                          const float *wp_dev, const float *bias_dev, const float *bn_mean_dev,
                          const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
                          float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
-                         int64_t ee_sub_in, int64_t ee_sub_out, void *stream);
+                         int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, const int32_t *hubinfo_dev,
+                         const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
+                         void *stream);
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 

@@ -20,16 +20,17 @@ _ptr = ctypes.c_void_p
 _SIGNATURES = {
     'mgcn_abi_version': (ctypes.c_int, []),
     'mgcn_last_error': (ctypes.c_char_p, []),
-    'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64] + [_ptr] * 10),
+    'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
+                                           _ptr] + [_ptr] * 5),
     'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
-                                          _ptr, _ptr, _i64, _i64, _i64, _ptr]),
+                                          _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
     'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _i64,
                                           _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
-                                            _i64, _i64, _ptr]),
+                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
@@ -99,26 +100,49 @@ def _same_device(*ts):
 
 
 # ------------------------------------------------------------------------------------------------
-def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward=True):
+HUB_THRESHOLD = int(os.environ.get('MGCN_HUB_THRESHOLD', '64'))   # slots per (half, destination) above which it is a hub
+HUB_CHUNK = int(os.environ.get('MGCN_HUB_CHUNK', '64'))             # slots per hub chunk
+
+
+def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward=True, hub_threshold=None,
+                   hub_chunk=None):
     """(1) Feeder. edge_index [2, 2E] int64, edge_type [2E] int64 (any device; copied to host).
-    Returns a dict of HOST tensors (see mgcn_csr_build_host)."""
+    Returns a dict of HOST tensors (see mgcn_csr_build_host); 'chunks' is trimmed to the chunks in use."""
     ei = edge_index.detach().to('cpu', torch.int64).contiguous()
     et = edge_type.detach().to('cpu', torch.int64).contiguous()
     if ei.dim() != 2 or ei.size(0) != 2 or ei.size(1) % 2 or et.numel() != ei.size(1):
         raise NativeError('csr_build: edge_index must be [2, 2E] and edge_type [2E]')
     E2, E, N = ei.size(1), ei.size(1) // 2, int(num_nodes)
+    thr = HUB_THRESHOLD if hub_threshold is None else int(hub_threshold)
+    chk = HUB_CHUNK if hub_chunk is None else int(hub_chunk)
+    max_chunks = (E2 // max(chk, 1) + E2 // max(thr, 1) + 2) if thr > 0 else 0
     out = dict(rowptr=torch.empty((2, N + 1), dtype=torch.int32), rec=torch.empty((E2, 4), dtype=torch.int32),
-               perm=torch.empty(E2, dtype=torch.int64))
+               perm=torch.empty(E2, dtype=torch.int64), hubinfo=torch.empty((2, N, 2), dtype=torch.int32),
+               chunks=torch.empty((max(max_chunks, 1), 4), dtype=torch.int32))
+    nch = ctypes.c_int64(0)
     if with_backward:
         out.update(slot_dst=torch.empty(E2, dtype=torch.int32), srcptr=torch.empty((2, N + 1), dtype=torch.int32),
                    srcslots=torch.empty(E2, dtype=torch.int32),
                    typeptr=torch.empty(num_rel_rows + 1, dtype=torch.int32),
                    typeslots=torch.empty(E2, dtype=torch.int32))
     p = lambda k: out[k].data_ptr() if k in out else None
-    _check(lib().mgcn_csr_build_host(N, E, int(num_rel_rows), ei.data_ptr(), et.data_ptr(), p('rowptr'), p('rec'),
-                                     p('perm'), p('slot_dst'), p('srcptr'), p('srcslots'), p('typeptr'),
-                                     p('typeslots')), 'mgcn_csr_build_host')
+    _check(lib().mgcn_csr_build_host(N, E, int(num_rel_rows), ei.data_ptr(), et.data_ptr(), thr, chk, p('rowptr'),
+                                     p('rec'), p('perm'), p('hubinfo'), p('chunks'), max_chunks, ctypes.byref(nch),
+                                     p('slot_dst'), p('srcptr'), p('srcslots'), p('typeptr'), p('typeslots')),
+           'mgcn_csr_build_host')
+    out['num_chunks'] = int(nch.value)
+    out['chunks'] = out['chunks'][:max(int(nch.value), 1)].contiguous()
     return out
+
+
+def _hub_args(csr, d, device, n0, n1):
+    """(hubinfo ptr, chunks ptr, chunk_begin, chunk_end, partial tensor) for a launch over destinations [n0, n1):
+    chunk sums live in a per-call buffer."""
+    c0, c1 = csr.chunk_range(n0, n1)
+    if c1 == c0:
+        return None, None, 0, 0, None
+    partial = torch.empty((c1 - c0, d), dtype=torch.float32, device=device)
+    return _dev(csr.hubinfo, torch.int32, 'hubinfo'), _dev(csr.chunks, torch.int32, 'chunks'), c0, c1, partial
 
 
 def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None):
@@ -146,11 +170,13 @@ def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=No
     n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
     if not 0 <= n0 <= n1 <= N:
         raise NativeError('aggregate_fwd: node range (%d, %d) outside [0, %d]' % (n0, n1, N))
+    hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
     _check(lib().mgcn_aggregate_fwd(
         N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
-        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, _stream(x)), 'mgcn_aggregate_fwd')
+        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, hub_info, hub_chunks, hub_c0, hub_c1,
+        _dev(hub_partial, torch.float32, 'partial', True), _stream(x)), 'mgcn_aggregate_fwd')
     return out
 
 
@@ -226,16 +252,17 @@ def pack_weights(w_cat, out=None):
 
 
 def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
-                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0)):
+                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0)):
     """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
     `w_packed` = pack_weights(stacked [3D, O] weights). With `node_range` = (n0, n1) only those destinations are
     computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
-    graph.GraphCSR.edge_table_shard) with `ee_sub` its two slot offsets."""
+    graph.GraphCSR.edge_table_shard) with `ee_sub` its three slot offsets (in-half, out-half, hub region)."""
     N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), int(d_out)
     n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
     if not 0 <= n0 <= n1 <= N:
         raise NativeError('layer_fwd_fused: node range (%d, %d) outside [0, %d]' % (n0, n1, N))
-    sharded = tuple(ee_sub) != (0, 0) or (ee is not None and ee.size(0) != 2 * E)
+    ee_sub = tuple(int(v) for v in ee_sub) + (0,) * (3 - len(ee_sub))
+    sharded = ee_sub != (0, 0, 0) or (ee is not None and ee.size(0) != 2 * E)
     _same_device(csr.rowptr, x, rel, loop_rel, ee, loop_edge, w_packed, bias, bn_mean, bn_var, bn_gamma, bn_beta, out)
     if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows - 1, D) or loop_rel.numel() != D or loop_edge.numel() != D:
         raise NativeError('layer_fwd_fused: x / rel / loop rows do not match the graph')
@@ -243,8 +270,8 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         raise NativeError('layer_fwd_fused: per-edge table must be contiguous (%d, %d)' % (2 * E, D))
     if ee is not None and sharded:
         rows = csr.shard_slot_counts(n0, n1)
-        if not ee_in_slot_order or tuple(ee.shape) != (rows[0] + rows[1], D) or not ee.is_contiguous() or \
-                tuple(int(v) for v in ee_sub) != csr.shard_ee_sub(n0, n1):
+        if not ee_in_slot_order or tuple(ee.shape) != (sum(rows), D) or not ee.is_contiguous() or \
+                ee_sub != csr.shard_ee_sub(n0, n1):
             raise NativeError('layer_fwd_fused: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
     if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
         raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
@@ -253,6 +280,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
             raise NativeError('layer_fwd_fused: per-column vectors must have %d elements' % O)
     if tuple(out.shape) != (n1 - n0, O):
         raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (n1 - n0, O))
+    hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
     _check(lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
@@ -260,8 +288,9 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(w_packed, torch.float32, 'w_packed'), _dev(bias, torch.float32, 'bias', True),
         _dev(bn_mean, torch.float32, 'bn_mean'), _dev(bn_var, torch.float32, 'bn_var'),
         _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
-        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), _stream(x)),
-        'mgcn_layer_fwd_fused')
+        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), int(ee_sub[2]),
+        hub_info, hub_chunks, hub_c0, hub_c1,
+        _dev(hub_partial, torch.float32, 'partial', True), _stream(x)), 'mgcn_layer_fwd_fused')
     return out
 
 

@@ -55,6 +55,11 @@ struct AggArgs {
   int64_t ldx, lda;
   int32_t n, e, d, rel_rows, ee_slot_order, modes;
   int32_t node0, nodes;  // destinations [node0, node0 + nodes) are processed
+  const int2 *hubinfo;   // [2][N] (first chunk, chunk count) or null
+  const int4 *chunks;    // [num_chunks] {slot begin, slot end, first chunk of the hub, chunks of the hub}
+  float *partial;        // [num_chunks][D] chunk sums; after the fold, row `first chunk` holds the hub's total
+  int32_t chunk0, nchunks;  // chunks [chunk0, chunk0 + nchunks) are in play; partial row = chunk - chunk0
+  int64_t ee_sub_hub;       // table row of hub slot s = s - ee_sub_hub (slot-ordered table shards)
 };
 
 // GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots in flight per group:
@@ -87,9 +92,9 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-  const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);
+  const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);   // absolute slot positions
   const int beg = rp[node], end = rp[node + 1];
-  const int64_t base = int64_t(mode) * p.e;
+  const int64_t base = 0;
   for (int s = beg; s < end; s += U) {
     int4 r[U];
 #pragma unroll
@@ -129,10 +134,137 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
       }
     }
   }
+  if (p.hubinfo) {  // a hub's own segment above is empty: its total was folded into the row of its first chunk
+    const int2 hi = p.hubinfo[int64_t(mode) * p.n + node];
+    if (hi.y > 0) {
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane_in_group + c * gs;
+        if (ch < nchunk) acc[c] = V::add(acc[c], V::load(p.partial + int64_t(hi.x - p.chunk0) * p.d + ch * VEC));
+      }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lane_in_group + c * gs;
     if (ch < nchunk) V::store(p.a + int64_t(node) * p.lda + mode * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// Hub pre-pass: one lane group per chunk of a hub destination's slots; same arithmetic and slot order as above.
+template <int VEC, int CPL, int U>
+__global__ __launch_bounds__(256) void agg_hub_kernel(AggArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lane_in_group = threadIdx.x & (gs - 1);
+  const int64_t chunk = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (chunk >= p.nchunks) return;
+  const int nchunk = p.d / VEC;
+  const int4 range = p.chunks[p.chunk0 + chunk];
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  for (int s = range.x; s < range.y; s += U) {
+    int4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s + u < range.y) r[u] = p.rec[s + u];
+    T xv[U][CPL], rv[U][CPL], ev[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u >= range.y) continue;
+      const float *xr = p.x + int64_t(r[u].x) * p.ldx;
+      const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
+      const float *er = p.ee ? p.ee + (p.ee_slot_order ? int64_t(s + u) - p.ee_sub_hub : int64_t(r[u].w)) * p.d : nullptr;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane_in_group + c * gs;
+        if (ch < nchunk) {
+          xv[u][c] = V::load(xr + ch * VEC);
+          rv[u][c] = V::load(rr + ch * VEC);
+          if (er) ev[u][c] = V::load(er + ch * VEC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u < range.y) {
+        const float w = __int_as_float(r[u].z);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = lane_in_group + c * gs;
+          if (ch < nchunk) {
+            T m = V::mul(xv[u][c], rv[u][c]);
+            if (p.ee) m = V::mul(m, ev[u][c]);
+            acc[c] = V::add(acc[c], V::muls(m, w));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane_in_group + c * gs;
+    if (ch < nchunk) V::store(p.partial + chunk * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// Hub fold: the workgroup of a hub's FIRST chunk adds the hub's chunk sums into that chunk's row (all other
+// workgroups leave at once). Lane group j adds chunks j, j+J, j+2J, ... in that order (U loads in flight), then
+// group 0 adds the J group sums in group order: a fixed summation tree, so results are reproducible.
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_hub_fold_kernel(AggArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  extern __shared__ float red[];  // [J][D]
+  const int4 me = p.chunks[p.chunk0 + blockIdx.x];
+  if (me.z != p.chunk0 + int(blockIdx.x) || me.w < 2) return;  // workgroup-uniform
+  float *rows = p.partial + int64_t(me.z - p.chunk0) * p.d;     // this hub's chunk sums
+  constexpr int U = 4;
+  const int gs = 1 << gs_log2, groups = 256 >> gs_log2;
+  const int grp = threadIdx.x >> gs_log2, lane_in_group = threadIdx.x & (gs - 1);
+  const int nchunk = p.d / VEC;
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  for (int k = grp; k < me.w; k += groups * U) {
+    T v[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k + u * groups;
+      if (kk >= me.w) continue;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane_in_group + c * gs;
+        if (ch < nchunk) v[u][c] = V::load(rows + int64_t(kk) * p.d + ch * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + u * groups >= me.w) continue;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lane_in_group + c * gs;
+        if (ch < nchunk) acc[c] = V::add(acc[c], v[u][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane_in_group + c * gs;
+    if (ch < nchunk) V::store(red + grp * p.d + ch * VEC, acc[c]);
+  }
+  __syncthreads();
+  if (grp != 0) return;
+  const int used = me.w < groups ? me.w : groups;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lane_in_group + c * gs;
+    if (ch >= nchunk) continue;
+    T tot = V::load(red + ch * VEC);
+    for (int j = 1; j < used; ++j) tot = V::add(tot, V::load(red + j * p.d + ch * VEC));
+    V::store(rows + ch * VEC, tot);
   }
 }
 
@@ -166,8 +298,9 @@ __global__ __launch_bounds__(256) void agg_bwd_gee_kernel(BwdArgs p, int gs_log2
   const int nchunk = p.d / VEC;
   const int4 r = p.rec[slot];
   const float w = __int_as_float(r.z);
-  const int half = slot >= p.e;
-  const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+  const int sd = p.slot_dst[slot];
+  const int half = (sd >> 31) & 1;
+  const float *gr = p.g + int64_t(sd & 0x7fffffff) * p.ldg + half * p.d;
   const float *xr = p.x + int64_t(r.x) * p.ldx;
   const float *rr = p.rel + int64_t(r.y) * p.d;
 #pragma unroll
@@ -197,10 +330,10 @@ __global__ __launch_bounds__(256) void agg_bwd_gx_kernel(BwdArgs p, int gs_log2)
     const int32_t *sp = p.srcptr + int64_t(half) * (p.n + 1);
     const int beg = sp[node], end = sp[node + 1];
     for (int i = beg; i < end; ++i) {
-      const int slot = p.srcslots[int64_t(half) * p.e + i];
+      const int slot = p.srcslots[i];
       const int4 r = p.rec[slot];
       const float w = __int_as_float(r.z);
-      const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+      const float *gr = p.g + int64_t(p.slot_dst[slot] & 0x7fffffff) * p.ldg + half * p.d;
       const float *rr = p.rel + int64_t(r.y) * p.d;
       const float *er = p.ee ? p.ee + int64_t(slot) * p.d : nullptr;
 #pragma unroll
@@ -255,8 +388,8 @@ __global__ __launch_bounds__(256) void agg_bwd_grel_partial_kernel(BwdArgs p, in
       out_row = int64_t(p.nchunks_type) + cur_type;  // a new type inside a chunk starts at typeptr[type]
     }
     const float w = __int_as_float(r.z);
-    const int half = slot >= p.e;
-    const float *gr = p.g + int64_t(p.slot_dst[slot]) * p.ldg + half * p.d;
+    const int sd = p.slot_dst[slot];
+    const float *gr = p.g + int64_t(sd & 0x7fffffff) * p.ldg + ((sd >> 31) & 1) * p.d;
     const float *xr = p.x + int64_t(r.x) * p.ldx;
     const float *er = p.ee ? p.ee + int64_t(slot) * p.d : nullptr;
 #pragma unroll
@@ -343,11 +476,75 @@ bool pick_geometry(int d, bool all_aligned, Geometry *g) {
 
 }  // namespace
 
+int mgcn::launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_rows, const mgcn_edge_rec *rec_dev,
+                              const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
+                              const float *ee_dev, int32_t ee_in_slot_order, int64_t ee_sub_hub,
+                              const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
+                              void *stream) {
+  const int64_t num_chunks = chunk_end - chunk_begin;
+  const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
+                       mgcn::aligned16(partial_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) && ldx % 4 == 0;
+  Geometry g;
+  if (!pick_geometry(dim, aligned, &g)) return mgcn::fail(MGCN_EUNSUPPORTED, "hub partials: dim %d too wide", dim);
+  AggArgs p = {};
+  p.rec = reinterpret_cast<const int4 *>(rec_dev);
+  p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev;
+  p.ldx = ldx; p.n = int32_t(num_nodes); p.d = dim; p.rel_rows = num_rel_rows; p.ee_slot_order = ee_in_slot_order;
+  p.chunks = reinterpret_cast<const int4 *>(chunks_dev);
+  p.partial = partial_dev;
+  p.chunk0 = int32_t(chunk_begin);
+  p.nchunks = int32_t(num_chunks);
+  p.ee_sub_hub = ee_sub_hub;
+  const int64_t threads = num_chunks << g.gs_log2;
+  const unsigned grid = unsigned((threads + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define MGCN_HUB_CASE(V_, C_, U_) hipLaunchKernelGGL((agg_hub_kernel<V_, C_, U_>), dim3(grid), dim3(256), 0, st, p, g.gs_log2)
+  if (g.vec == 4) {
+    switch (g.cpl) {
+      case 1: MGCN_HUB_CASE(4, 1, 4); break;
+      case 2: MGCN_HUB_CASE(4, 2, 2); break;
+      case 4: MGCN_HUB_CASE(4, 4, 1); break;
+      default: MGCN_HUB_CASE(4, 8, 1); break;
+    }
+  } else {
+    switch (g.cpl) {
+      case 1: MGCN_HUB_CASE(1, 1, 4); break;
+      case 2: MGCN_HUB_CASE(1, 2, 2); break;
+      case 4: MGCN_HUB_CASE(1, 4, 1); break;
+      default: MGCN_HUB_CASE(1, 8, 1); break;
+    }
+  }
+#undef MGCN_HUB_CASE
+  MGCN_CHECK_LAUNCH("agg_hub_kernel");
+  const size_t lds = size_t(256 >> g.gs_log2) * size_t(dim) * sizeof(float);
+#define MGCN_FOLD_CASE(V_, C_) hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, p, g.gs_log2)
+  if (g.vec == 4) {
+    switch (g.cpl) {
+      case 1: MGCN_FOLD_CASE(4, 1); break;
+      case 2: MGCN_FOLD_CASE(4, 2); break;
+      case 4: MGCN_FOLD_CASE(4, 4); break;
+      default: MGCN_FOLD_CASE(4, 8); break;
+    }
+  } else {
+    switch (g.cpl) {
+      case 1: MGCN_FOLD_CASE(1, 1); break;
+      case 2: MGCN_FOLD_CASE(1, 2); break;
+      case 4: MGCN_FOLD_CASE(1, 4); break;
+      default: MGCN_FOLD_CASE(1, 8); break;
+    }
+  }
+#undef MGCN_FOLD_CASE
+  MGCN_CHECK_LAUNCH("agg_hub_fold_kernel");
+  return MGCN_OK;
+}
+
 extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                                   const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                                   int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
                                   int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
-                                  int64_t node_begin, int64_t node_end, void *stream) {
+                                  int64_t node_begin, int64_t node_end, const int32_t *hubinfo_dev,
+                                  const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
+                                  void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_fwd: bad sizes");
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "aggregate_fwd: sizes exceed int32");
@@ -357,6 +554,10 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   const int modes = loop_edge_dev ? 3 : 2;
   MGCN_REQUIRE(ldx >= dim && lda >= int64_t(modes) * dim, "aggregate_fwd: ldx/lda too small");
   MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "aggregate_fwd: bad node range");
+  const int64_t num_chunks = chunk_end - chunk_begin;
+  MGCN_REQUIRE(chunk_begin >= 0 && num_chunks >= 0 && chunk_end < (int64_t(1) << 31) &&
+                   (num_chunks == 0 || (hubinfo_dev && chunks_dev && partial_dev && mgcn::aligned16(partial_dev))),
+               "aggregate_fwd: hub chunks need hubinfo / chunks / a 16-byte aligned partial buffer");
   if (node_end == node_begin) return MGCN_OK;
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
                        mgcn::aligned16(a_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
@@ -382,6 +583,17 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   p.modes = modes;
   p.node0 = int32_t(node_begin);
   p.nodes = int32_t(node_end - node_begin);
+  p.hubinfo = num_chunks > 0 ? reinterpret_cast<const int2 *>(hubinfo_dev) : nullptr;
+  p.chunks = reinterpret_cast<const int4 *>(chunks_dev);
+  p.partial = partial_dev;
+  p.chunk0 = int32_t(chunk_begin);
+  p.nchunks = int32_t(num_chunks);
+  p.ee_sub_hub = 0;
+  if (num_chunks > 0) {
+    if (int rc = mgcn::launch_hub_partials(num_nodes, dim, num_rel_rows, rec_dev, x_dev, ldx, rel_dev, loop_rel_dev, ee_dev,
+                                           ee_in_slot_order, 0, chunks_dev, chunk_begin, chunk_end, partial_dev, stream))
+      return rc;
+  }
   {
     const int64_t threads = (int64_t(modes) * p.nodes) << g.gs_log2;
     const unsigned grid = unsigned((threads + 255) / 256);

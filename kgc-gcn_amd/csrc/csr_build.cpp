@@ -20,7 +20,9 @@ extern "C" const char *mgcn_last_error(void) { return mgcn::error_buffer(); }
 
 extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_rel_rows,
                                    const int64_t *edge_index_host, const int64_t *edge_type_host,
-                                   int32_t *rowptr_host, mgcn_edge_rec *rec_host, int64_t *perm_host,
+                                   int64_t hub_threshold, int64_t hub_chunk, int32_t *rowptr_host,
+                                   mgcn_edge_rec *rec_host, int64_t *perm_host, int32_t *hubinfo_host,
+                                   int32_t *chunks_host, int64_t max_chunks, int64_t *num_chunks_host,
                                    int32_t *slot_dst_host, int32_t *srcptr_host, int32_t *srcslots_host,
                                    int32_t *typeptr_host, int32_t *typeslots_host) {
   const int64_t N = num_nodes, E = num_edges_half, E2 = 2 * num_edges_half;
@@ -28,6 +30,14 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
   MGCN_REQUIRE(N < (int64_t(1) << 31) - 1 && E2 < (int64_t(1) << 31) - 1, "csr_build: sizes exceed int32 slots");
   MGCN_REQUIRE(rowptr_host && (E == 0 || (rec_host && perm_host)), "csr_build: null output");
   MGCN_REQUIRE(E == 0 || (edge_index_host && edge_type_host), "csr_build: null input");
+  const bool hubs = hub_threshold > 0;
+  MGCN_REQUIRE(!hubs || (hub_chunk > 0 && hubinfo_host && chunks_host && num_chunks_host),
+               "csr_build: hub splitting needs hub_chunk > 0 and the hubinfo / chunks / num_chunks outputs");
+  const bool bwd = srcptr_host != nullptr;
+  MGCN_REQUIRE(bwd == (typeptr_host != nullptr) &&
+                   (E == 0 || (bwd == (slot_dst_host != nullptr) && bwd == (srcslots_host != nullptr) &&
+                               bwd == (typeslots_host != nullptr))),
+               "csr_build: backward index outputs must be given all together or not at all");
   const int64_t *src = edge_index_host, *dst = edge_index_host + E2;
   for (int64_t e = 0; e < E2; ++e) {
     MGCN_REQUIRE(src[e] >= 0 && src[e] < N && dst[e] >= 0 && dst[e] < N,
@@ -37,27 +47,59 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
                  "csr_build: edge %lld type %lld outside [0, %lld)", (long long)e,
                  (long long)edge_type_host[e], (long long)num_rel_rows);
   }
+  // ---- pass 1: destination counts per half; a destination with more than hub_threshold slots in a half is a hub
+  std::vector<int32_t> cnt(2 * N, 0);
+  for (int h = 0; h < 2; ++h)
+    for (int64_t e = h * E; e < (h + 1) * E; ++e) cnt[h * N + dst[e]]++;
+  auto is_hub = [&](int h, int64_t n) { return hubs && cnt[h * N + n] > hub_threshold; };
+  // ---- slot layout: [in-half non-hub segments | out-half non-hub segments | hub segments (node, half order)].
+  // rowptr holds ABSOLUTE slot positions of the non-hub segments (a hub's segment there is empty).
+  int64_t pos = 0;
+  for (int h = 0; h < 2; ++h) {
+    int32_t *rowptr = rowptr_host + h * (N + 1);
+    for (int64_t n = 0; n < N; ++n) {
+      rowptr[n] = int32_t(pos);
+      if (!is_hub(h, n)) pos += cnt[h * N + n];
+    }
+    rowptr[N] = int32_t(pos);
+  }
+  std::vector<int32_t> cursor(2 * N);
+  for (int h = 0; h < 2; ++h)
+    for (int64_t n = 0; n < N; ++n) cursor[h * N + n] = rowptr_host[h * (N + 1) + n];
+  int64_t nchunks = 0;
+  if (hubinfo_host)
+    for (int64_t i = 0; i < 4 * N; ++i) hubinfo_host[i] = (i & 1) ? 0 : -1;  // (first chunk, chunk count) = (-1, 0)
+  if (hubs) {
+    for (int64_t n = 0; n < N; ++n)       // node-major: the hubs of a destination range own ONE run of slots / chunks
+      for (int h = 0; h < 2; ++h) {
+        if (!is_hub(h, n)) continue;
+        const int64_t len = cnt[h * N + n], nch = (len + hub_chunk - 1) / hub_chunk;
+        MGCN_REQUIRE(nchunks + nch <= max_chunks, "csr_build: chunk table too small (%lld)", (long long)max_chunks);
+        hubinfo_host[(h * N + n) * 2 + 0] = int32_t(nchunks);
+        hubinfo_host[(h * N + n) * 2 + 1] = int32_t(nch);
+        for (int64_t k = 0; k < nch; ++k) {
+          int32_t *c = chunks_host + (nchunks + k) * 4;   // {begin, end, first chunk of the hub, chunks of the hub}
+          c[0] = int32_t(pos + k * hub_chunk);
+          c[1] = int32_t(pos + (k + 1 < nch ? (k + 1) * hub_chunk : len));
+          c[2] = int32_t(nchunks);
+          c[3] = int32_t(nch);
+        }
+        nchunks += nch;
+        cursor[h * N + n] = int32_t(pos);
+        pos += len;
+      }
+  }
+  if (num_chunks_host) *num_chunks_host = nchunks;
+  // ---- pass 2: stable fill in edge-id order; norms folded into the records
   std::vector<float> cinv(N);
-  std::vector<int32_t> cursor(N + 1);
-  const bool bwd = srcptr_host != nullptr;
-  MGCN_REQUIRE(bwd == (typeptr_host != nullptr) &&
-                   (E == 0 || (bwd == (slot_dst_host != nullptr) && bwd == (srcslots_host != nullptr) &&
-                               bwd == (typeslots_host != nullptr))),
-               "csr_build: backward index outputs must be given all together or not at all");
   for (int h = 0; h < 2; ++h) {
     const int64_t lo = h * E;
-    int32_t *rowptr = rowptr_host + h * (N + 1);
     // degree by SOURCE within the half (model.py:74-75), deg^-1/2 with inf -> 0 (model.py:76-77)
     std::vector<int32_t> deg(N, 0);
     for (int64_t e = lo; e < lo + E; ++e) deg[src[e]]++;
     for (int64_t n = 0; n < N; ++n) cinv[n] = deg[n] ? 1.0f / std::sqrt(static_cast<float>(deg[n])) : 0.0f;
-    // counting sort by destination, stable in edge id
-    std::memset(rowptr, 0, sizeof(int32_t) * (N + 1));
-    for (int64_t e = lo; e < lo + E; ++e) rowptr[dst[e] + 1]++;
-    for (int64_t n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
-    std::memcpy(cursor.data(), rowptr, sizeof(int32_t) * (N + 1));
     for (int64_t e = lo; e < lo + E; ++e) {
-      const int64_t slot = lo + cursor[dst[e]]++;
+      const int64_t slot = cursor[h * N + dst[e]]++;
       mgcn_edge_rec r;
       r.src = static_cast<int32_t>(src[e]);
       r.type = static_cast<int32_t>(edge_type_host[e]);
@@ -65,18 +107,26 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
       r.eid = static_cast<int32_t>(e);
       rec_host[slot] = r;
       perm_host[slot] = e;
-      if (bwd) slot_dst_host[slot] = static_cast<int32_t>(dst[e]);
-    }
-    if (bwd) {  // slots of this half grouped by source, ascending slot id
-      int32_t *srcptr = srcptr_host + h * (N + 1);
-      std::memset(srcptr, 0, sizeof(int32_t) * (N + 1));
-      for (int64_t s = lo; s < lo + E; ++s) srcptr[rec_host[s].src + 1]++;
-      for (int64_t n = 0; n < N; ++n) srcptr[n + 1] += srcptr[n];
-      std::memcpy(cursor.data(), srcptr, sizeof(int32_t) * (N + 1));
-      for (int64_t s = lo; s < lo + E; ++s) srcslots_host[lo + cursor[rec_host[s].src]++] = static_cast<int32_t>(s);
+      if (bwd) slot_dst_host[slot] = static_cast<int32_t>(dst[e]) | (h ? int32_t(0x80000000u) : 0);  // bit 31 = half
     }
   }
-  if (bwd) {  // all slots grouped by relation row, ascending slot id
+  if (bwd) {
+    // slots grouped by (half, source), ascending slot id; srcptr positions index srcslots directly
+    std::vector<int32_t> scount(2 * N, 0);
+    for (int64_t s = 0; s < E2; ++s) scount[((slot_dst_host[s] >> 31) & 1) * N + rec_host[s].src]++;
+    int64_t sp = 0;
+    for (int h = 0; h < 2; ++h) {
+      for (int64_t n = 0; n < N; ++n) {
+        srcptr_host[h * (N + 1) + n] = int32_t(sp);
+        sp += scount[h * N + n];
+      }
+      srcptr_host[h * (N + 1) + N] = int32_t(sp);
+    }
+    std::vector<int32_t> sc(2 * N);
+    for (int h = 0; h < 2; ++h)
+      for (int64_t n = 0; n < N; ++n) sc[h * N + n] = srcptr_host[h * (N + 1) + n];
+    for (int64_t s = 0; s < E2; ++s) srcslots_host[sc[((slot_dst_host[s] >> 31) & 1) * N + rec_host[s].src]++] = int32_t(s);
+    // all slots grouped by relation row, ascending slot id
     std::vector<int32_t> tcur(num_rel_rows + 1, 0);
     std::memset(typeptr_host, 0, sizeof(int32_t) * (num_rel_rows + 1));
     for (int64_t s = 0; s < E2; ++s) typeptr_host[rec_host[s].type + 1]++;

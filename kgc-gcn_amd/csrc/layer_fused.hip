@@ -42,7 +42,10 @@ struct FusedArgs {
   int64_t ldx, ldo;
   int32_t n, e, d, o, rel_rows, ee_slot_order, gs_log2;
   int32_t node0, node1;   // destinations [node0, node1) are this launch's (this rank's) share; out row 0 = node0
-  int64_t ee_sub[2];      // slot-order per-edge table shard: row of global slot s of half h = s - ee_sub[h]
+  int64_t ee_sub[2];      // slot-order per-edge table shard: row of (absolute) slot s of half h = s - ee_sub[h]
+  const int2 *hubinfo;    // [2][N] (first chunk, chunk count) or null
+  const float *partial;   // [chunks in play][D]; row (first chunk - chunk0) of a hub holds its folded total (pre-pass)
+  int32_t chunk0;
   int32_t ablate;  // timing diagnostics only (MGCN_FUSED_ABLATE): bit 0 skips the gather, bit 1 the MFMA loop
   float bn_eps;
 };
@@ -110,11 +113,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
           // the group's rpg + 1 row pointers: lane i of the group holds the pointer of destination g_lo + i
           int node = r0 + g_lo + (lig <= rpg ? lig : rpg);
           node = node < p.node1 ? node : p.node1;
-          const int myrp = p.rowptr[int64_t(mode) * (p.n + 1) + node];
-          const int64_t base = int64_t(mode) * p.e;
+          const int myrp = p.rowptr[int64_t(mode) * (p.n + 1) + node];   // absolute slot position
+          int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination g_lo + i
+          if (p.hubinfo && lig < rpg && node < p.node1) myhub = p.hubinfo[int64_t(mode) * p.n + node];
+          const int64_t base = 0;
           const int end = __shfl(myrp, glane0 + rpg);
           int row = g_lo, nb = __shfl(myrp, glane0 + 1);
           float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+          auto add_hub = [&](int r) {   // a hub's own run is empty: its total sits in the row of its first chunk (group-uniform)
+            if (!p.hubinfo) return;
+            const int first = __shfl(myhub.x, glane0 + (r - g_lo)), cnt = __shfl(myhub.y, glane0 + (r - g_lo));
+            if (cnt > 0) {
+              const float4 ps = *reinterpret_cast<const float4 *>(p.partial + int64_t(first - p.chunk0) * p.d + coff);
+              sum = make_float4(sum.x + ps.x, sum.y + ps.y, sum.z + ps.z, sum.w + ps.w);
+            }
+          };
           for (int s = __shfl(myrp, glane0); s < end; s += U) {
             int4 r[U];
 #pragma unroll
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
             for (int u = 0; u < U; ++u) {
               if (s + u < end) {
                 while (s + u >= nb) {  // group-uniform: the run of destination `row` is complete
+                  add_hub(row);
                   if (col_ok) {
                     float *dst = at + row * lda + lig * 4;
                     *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
@@ -151,6 +165,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
             }
           }
           for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
+            add_hub(row);
             if (col_ok) {
               float *dst = at + row * lda + lig * 4;
               *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
@@ -312,7 +327,9 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                     const float *wp_dev, const float *bias_dev, const float *bn_mean_dev,
                                     const float *bn_var_dev, const float *bn_gamma_dev, const float *bn_beta_dev,
                                     float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
-                                    int64_t ee_sub_in, int64_t ee_sub_out, void *stream) {
+                                    int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub,
+                                    const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t chunk_begin,
+                                    int64_t chunk_end, float *partial_dev, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
                "layer_fwd_fused: bad sizes");
   MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "layer_fwd_fused: bad node range");
@@ -328,10 +345,23 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   if (!aligned || dim_in % 4 != 0 || dim_in > 256 || dim_out % 4 != 0 || dim_out > 208)
     return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, D %% 4 == 0, D <= 256, "
                       "O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
+  const int64_t num_chunks = chunk_end - chunk_begin;
+  MGCN_REQUIRE(chunk_begin >= 0 && num_chunks >= 0 && chunk_end < (int64_t(1) << 31) &&
+                   (num_chunks == 0 || (hubinfo_dev && chunks_dev && partial_dev && mgcn::aligned16(partial_dev))),
+               "layer_fwd_fused: hub chunks need hubinfo / chunks / a 16-byte aligned partial buffer");
   if (node_end == node_begin) return MGCN_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (num_chunks > 0) {
+    if (int rc = mgcn::launch_hub_partials(num_nodes, dim_in, num_rel_rows, rec_dev, x_dev, ldx, rel_dev, loop_rel_dev,
+                                           ee_dev, ee_in_slot_order, ee_sub_hub, chunks_dev, chunk_begin, chunk_end,
+                                           partial_dev, stream))
+      return rc;
+  }
   const int nt = pick_nt(dim_out);
   FusedArgs p = {};
+  p.hubinfo = num_chunks > 0 ? reinterpret_cast<const int2 *>(hubinfo_dev) : nullptr;
+  p.partial = partial_dev;
+  p.chunk0 = int32_t(chunk_begin);
   p.node0 = int32_t(node_begin); p.node1 = int32_t(node_end); p.ee_sub[0] = ee_sub_in; p.ee_sub[1] = ee_sub_out;
   p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;

@@ -13,10 +13,13 @@ from . import _native
 class GraphCSR(object):
     """Device-resident slot arrays produced by mgcn_csr_build_host (include/mgcn_hip.h (1))."""
 
-    _FIELDS = ('rowptr', 'rec', 'perm', 'slot_dst', 'srcptr', 'srcslots', 'typeptr', 'typeslots')
+    _FIELDS = ('rowptr', 'rec', 'perm', 'hubinfo', 'chunks', 'slot_dst', 'srcptr', 'srcslots', 'typeptr', 'typeslots')
 
-    def __init__(self, num_nodes, num_rel_rows, edge_index, edge_type, device, with_backward=True):
-        host = _native.csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward)
+    def __init__(self, num_nodes, num_rel_rows, edge_index, edge_type, device, with_backward=True, hub_threshold=None,
+                 hub_chunk=None):
+        host = _native.csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward, hub_threshold,
+                                      hub_chunk)
+        self.num_chunks = host['num_chunks']                     # hub chunks (0: no destination is a hub)
         self.num_nodes = int(num_nodes)
         self.num_edges_half = int(edge_index.size(1)) // 2
         self.num_rel_rows = int(num_rel_rows)
@@ -24,6 +27,13 @@ class GraphCSR(object):
         for k in self._FIELDS:
             setattr(self, k, host[k].to(device) if k in host else None)
         self._inv_perm = None
+        # hubs sit in node order, so destinations [n0, n1) own chunks [chunkptr[n0], chunkptr[n1]) (host-side index)
+        if self.num_chunks:
+            per_node = host['hubinfo'][:, :, 1].sum(0, dtype=torch.int64)
+            self._chunkptr = torch.cat([per_node.new_zeros(1), per_node.cumsum(0)]).tolist()
+            self._chunk_slot0 = host['chunks'][:self.num_chunks, 0].tolist() + [2 * self.num_edges_half]
+        else:
+            self._chunkptr, self._chunk_slot0 = None, None
 
     @property
     def device(self):
@@ -52,24 +62,32 @@ class GraphCSR(object):
         cache = self.__dict__.setdefault('_shard_cache', {})
         if key not in cache:
             rp = self.rowptr[:, [key[0], key[1]]].cpu().tolist()      # [[in0, in1], [out0, out1]] slot positions
-            cache[key] = ((rp[0][0], rp[0][1]), (rp[1][0], rp[1][1]))
+            c0, c1 = self.chunk_range(*key)
+            hub = (self._chunk_slot0[c0], self._chunk_slot0[c1]) if self.num_chunks else (0, 0)
+            cache[key] = ((rp[0][0], rp[0][1]), (rp[1][0], rp[1][1]), hub)
         return cache[key]
 
+    def chunk_range(self, n0, n1):
+        """Hub chunks [c0, c1) that belong to destinations [n0, n1)."""
+        if not self.num_chunks:
+            return 0, 0
+        return self._chunkptr[int(n0)], self._chunkptr[int(n1)]
+
     def shard_slot_counts(self, n0, n1):
-        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
-        return i1 - i0, o1 - o0
+        (i0, i1), (o0, o1), (h0, h1) = self._shard_bounds(n0, n1)
+        return i1 - i0, o1 - o0, h1 - h0
 
     def shard_ee_sub(self, n0, n1):
-        """(ee_sub_in, ee_sub_out) for a table that holds only the slots of destinations [n0, n1)."""
-        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
-        return i0, self.num_edges_half + o0 - (i1 - i0)
+        """(ee_sub_in, ee_sub_out, ee_sub_hub) for a table that holds only the slots of destinations [n0, n1):
+        the row of absolute slot s in that table is s - ee_sub[region]."""
+        (i0, i1), (o0, o1), (h0, h1) = self._shard_bounds(n0, n1)
+        return i0, o0 - (i1 - i0), h0 - (i1 - i0) - (o1 - o0)
 
     def edge_table_shard(self, table_slot_order, n0, n1):
-        """Rows of a slot-ordered per-edge table that destinations [n0, n1) need: their in-half slots, then their
-        out-half slots (each a contiguous run). 1/W of the table per rank for a balanced partition."""
-        (i0, i1), (o0, o1) = self._shard_bounds(n0, n1)
-        e = self.num_edges_half
-        return torch.cat([table_slot_order[i0:i1], table_slot_order[e + o0:e + o1]], dim=0).contiguous()
+        """Rows of a slot-ordered per-edge table that destinations [n0, n1) need: their in-half slots, their out-half
+        slots, then the slots of their hubs (each a contiguous run). 1/W of the table per rank for a balanced partition."""
+        (i0, i1), (o0, o1), (h0, h1) = self._shard_bounds(n0, n1)
+        return torch.cat([table_slot_order[i0:i1], table_slot_order[o0:o1], table_slot_order[h0:h1]], dim=0).contiguous()
 
     def norms(self):
         """Per-slot degree norm (f32 view of the record's third word)."""

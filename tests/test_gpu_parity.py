@@ -46,7 +46,7 @@ def test_aggregate_bit_exact_vs_oracle(pkg, oracle, case, ee_mode):
     N, R = int(g['dl_num_entity']), int(g['dl_num_relation'])
     ee = sd['edge_embeddings'] if ee_mode != 'none' else torch.ones_like(sd['edge_embeddings'])
     _, want = oracle.aggregate_then_weight(sd, 'conv1.', sd['entity_embedding'], ei, ea[0], ee, sd['relation_embedding'])
-    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV)
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV, hub_threshold=0)      # strict order: no destination is split
     x = sd['entity_embedding'].to(DEV)
     rel = torch.cat([sd['relation_embedding'], sd['conv1.loop_rel']]).to(DEV)
     D = x.size(1)
@@ -437,10 +437,12 @@ def test_integration_stub(pkg):
     np.testing.assert_allclose(out.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize('hubs', [False, True])
 @pytest.mark.parametrize('case', ALL_CASES)
-def test_destination_ranges_with_table_shards(pkg, case):
+def test_destination_ranges_with_table_shards(pkg, case, hubs):
     """One process plays three ranks in turn: each computes its destination range from its shard of the per-edge table
-    (fused kernel, node_range + ee_sub); the concatenation is bit-identical to the full launch."""
+    (fused kernel, node_range + ee_sub); the concatenation is bit-identical to the full launch — also when destinations
+    above 3 slots are hubs cut into chunks of 2 (their slots form a third run of the shard)."""
     g = golden(case)
     sd = g.state_dict()
     ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
@@ -449,7 +451,8 @@ def test_destination_ranges_with_table_shards(pkg, case):
     conv = pkg.MGCNConv(D, O, 2 * R, bias='conv1.bias' in sd)
     conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
     conv.to(DEV).eval()
-    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV)
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV, hub_threshold=3 if hubs else 0, hub_chunk=2)
+    assert bool(csr.num_chunks) == hubs
     x, rel = sd['entity_embedding'].to(DEV), sd['relation_embedding'].to(DEV)
     table = sd['edge_embeddings'].to(DEV).index_select(0, csr.perm)
     _, wpack = conv.derived_weights()
@@ -462,7 +465,7 @@ def test_destination_ranges_with_table_shards(pkg, case):
                             conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
                             node_range=(n0, n1), ee_sub=ee_sub)
         return out
-    full = run(0, N, table, (0, 0))
+    full = run(0, N, table, (0, 0, 0))
     np.testing.assert_allclose(full.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
     b = pkg.dist.shard_bounds(N, 3)
     parts = [run(b[r], b[r + 1], csr.edge_table_shard(table, b[r], b[r + 1]), csr.shard_ee_sub(b[r], b[r + 1]))
@@ -470,3 +473,46 @@ def test_destination_ranges_with_table_shards(pkg, case):
     assert torch.equal(torch.cat(parts, dim=0), full)
     with pytest.raises(nat.NativeError):                       # a shard that does not belong to the range is refused
         run(b[0], b[1], csr.edge_table_shard(table, b[1], b[2]), csr.shard_ee_sub(b[1], b[2]))
+
+
+@pytest.mark.parametrize('case', ['syn_b', 'syn_c'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_hub_splitting_forward_and_backward(pkg, oracle, case, fused, monkeypatch):
+    """Hubs forced by a tiny threshold (8 slots, chunks of 5): the layer output matches the golden / oracle within the
+    float tolerance (chunked sums change only the rounding order), two runs are bit-identical (no atomics), and the
+    gradients through the HIP backward match the reference's."""
+    g = golden(case)
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    N, R = int(g['dl_num_entity']), int(g['dl_num_relation'])
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, 2 * R, bias='conv1.bias' in sd)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, ea[0], DEV, hub_threshold=8, hub_chunk=5)
+    assert csr.num_chunks > 0
+    if not fused:
+        monkeypatch.setattr(pkg._native, 'fused_supported', lambda d_in, d_out: False)
+        conv._derived_stamp = None
+    x, rel = sd['entity_embedding'].to(DEV), sd['relation_embedding'].to(DEV)
+    ee = sd['edge_embeddings'].to(DEV)
+    with torch.no_grad():
+        a1, r1 = conv(x, ei.to(DEV), ea[0].to(DEV), None, ee, rel, csr=csr)
+        a2, _ = conv(x, ei.to(DEV), ea[0].to(DEV), None, ee, rel, csr=csr)
+    assert torch.equal(a1, a2)
+    np.testing.assert_allclose(a1.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=5e-5)
+    # backward (training mode, BN batch statistics), against the oracle's autograd
+    conv.train()
+    conv.drop.p = 0.0
+    xg, eg, rg = x.clone().requires_grad_(True), ee.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    ent, allrel = conv(xg, ei.to(DEV), ea[0].to(DEV), None, eg, rg, csr=csr)
+    G = torch.randn(ent.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (ent * G).sum().backward()
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in sd.items()}
+    oee = osd['edge_embeddings'].index_select(0, ea[1])
+    o_ent, _ = oracle.layer_forward(osd, 'conv1.', osd['entity_embedding'], ei, ea[0], oee, osd['relation_embedding'], training=True)
+    (o_ent * G.cpu()).sum().backward()
+    for got, want, name in ((xg.grad, osd['entity_embedding'].grad, 'x'), (eg.grad, osd['edge_embeddings'].grad, 'ee'),
+                            (rg.grad, osd['relation_embedding'].grad, 'rel')):
+        scale = float(want.abs().max()) + 1e-12
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-3, atol=5e-5 * scale + 1e-9, err_msg=name)

@@ -27,26 +27,100 @@ def test_feeder_bit_exact(pkg, case):
     g = golden(case)
     ei, et = g.t('dl_edge_index'), g.t('dl_edge_attr')[0]
     N, R, E = int(g['dl_num_entity']), int(g['dl_num_relation']), int(g['dl_num_edge'])
-    h = pkg._native.csr_build_host(N, 2 * R + 1, ei, et)
+    h = pkg._native.csr_build_host(N, 2 * R + 1, ei, et, hub_threshold=0)      # strict layout: no destination is split
+    assert h['num_chunks'] == 0 and bool((h['hubinfo'][:, :, 0] == -1).all())
     for half in range(2):
         lo = half * E
         dst = ei[1, lo:lo + E].numpy()
         order = np.argsort(dst, kind='stable') + lo                       # (dst, edge id) order
         assert np.array_equal(h['perm'][lo:lo + E].numpy(), order)
-        assert np.array_equal(h['rowptr'][half].numpy(), np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]))
+        assert np.array_equal(h['rowptr'][half].numpy(), lo + np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]))
         assert np.array_equal(h['rec'][lo:lo + E, 0].numpy(), ei[0].numpy()[order])
         assert np.array_equal(h['rec'][lo:lo + E, 1].numpy(), et.numpy()[order])
         assert np.array_equal(h['rec'][lo:lo + E, 3].numpy(), order)
-        assert np.array_equal(h['slot_dst'][lo:lo + E].numpy(), dst[order - lo])
+        sd = h['slot_dst'][lo:lo + E].numpy()
+        assert np.array_equal(sd & 0x7fffffff, dst[order - lo]) and bool((((sd >> 31) & 1) == half).all())
         src_of_slot = h['rec'][lo:lo + E, 0].numpy()
         assert np.array_equal(h['srcslots'][lo:lo + E].numpy(), np.argsort(src_of_slot, kind='stable') + lo)
-        assert np.array_equal(h['srcptr'][half].numpy(), np.concatenate([[0], np.cumsum(np.bincount(src_of_slot, minlength=N))]))
+        assert np.array_equal(h['srcptr'][half].numpy(), lo + np.concatenate([[0], np.cumsum(np.bincount(src_of_slot, minlength=N))]))
     typ = h['rec'][:, 1].numpy()
     assert np.array_equal(h['typeslots'].numpy(), np.argsort(typ, kind='stable'))
     assert np.array_equal(h['typeptr'].numpy(), np.concatenate([[0], np.cumsum(np.bincount(typ, minlength=2 * R + 1))]))
     norms = h['rec'][:, 2].contiguous().view(torch.float32).numpy()
     want = np.concatenate([g['norm_in'], g['norm_out']])[h['perm'].numpy()]
     assert np.array_equal(norms, want)                                    # f32 bit-exact (model.py:72-80)
+
+
+@pytest.mark.parametrize('case', ['syn_b', 'syn_c'])
+def test_feeder_hub_splitting(pkg, case):
+    """Destinations with more than `hub_threshold` slots in a half leave the main CSR; their slots, still in edge-id
+    order, are cut into chunks of `hub_chunk`. Every edge lands in exactly one slot."""
+    g = golden(case)
+    ei, et = g.t('dl_edge_index'), g.t('dl_edge_attr')[0]
+    N, R, E = int(g['dl_num_entity']), int(g['dl_num_relation']), int(g['dl_num_edge'])
+    T, C = 8, 5
+    h = pkg._native.csr_build_host(N, 2 * R + 1, ei, et, hub_threshold=T, hub_chunk=C)
+    perm = h['perm'].numpy()
+    assert np.array_equal(np.sort(perm), np.arange(2 * E))
+    assert np.array_equal(h['rec'][:, 3].numpy(), perm) and np.array_equal(h['rec'][:, 0].numpy(), ei[0].numpy()[perm])
+    hubs = 0
+    for half in range(2):
+        lo = half * E
+        dst = ei[1, lo:lo + E].numpy()
+        cnt = np.bincount(dst, minlength=N)
+        rp = h['rowptr'][half].numpy()
+        for n in range(N):
+            want = np.nonzero(dst == n)[0] + lo                          # this destination's edges, edge-id order
+            first, nch = h['hubinfo'][half, n].tolist()
+            if cnt[n] > T:
+                hubs += 1
+                assert rp[n + 1] == rp[n] and nch == -(-cnt[n] // C)
+                ranges = h['chunks'][first:first + nch, :2].numpy()
+                assert bool((h['chunks'][first:first + nch, 2] == first).all()) and bool((h['chunks'][first:first + nch, 3] == nch).all())
+                assert all(0 < e - b <= C for b, e in ranges) and all(ranges[k][1] == ranges[k + 1][0] for k in range(nch - 1))
+                assert np.array_equal(perm[ranges[0][0]:ranges[-1][1]], want)
+            else:
+                assert (first, nch) == (-1, 0)
+                assert np.array_equal(perm[rp[n]:rp[n + 1]], want)
+    assert hubs > 0 and h['num_chunks'] == int(h['hubinfo'][:, :, 1].sum())
+    assert h['rowptr'][1, 0] == h['rowptr'][0, N]                            # out-half main region follows the in-half one
+
+
+def test_destination_shards_with_hubs(pkg):
+    """Host index for the destination partition: the three runs of a rank's table shard (in-half, out-half, hub region)
+    hold exactly the slots whose destination the rank owns, at row = slot - ee_sub[region]; the rank's hub chunks are
+    one run of the chunk table (hub region in node order)."""
+    g = golden('syn_c')
+    ei, et = g.t('dl_edge_index'), g.t('dl_edge_attr')[0]
+    N, R, E = int(g['dl_num_entity']), int(g['dl_num_relation']), int(g['dl_num_edge'])
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, et, 'cpu', hub_threshold=8, hub_chunk=5)
+    assert csr.num_chunks > 0
+    firsts = csr.hubinfo[:, :, 0].t().reshape(-1)                            # (node, half) order
+    firsts = firsts[firsts >= 0]
+    assert bool((firsts[1:] > firsts[:-1]).all())
+    table = torch.arange(2 * E, dtype=torch.float32).unsqueeze(1)           # row value = slot id
+    dst = csr.slot_dst & 0x7fffffff
+    b = pkg.dist.shard_bounds(N, 3)
+    chunks_seen = 0
+    for r in range(3):
+        n0, n1 = b[r], b[r + 1]
+        shard = csr.edge_table_shard(table, n0, n1)[:, 0].long()
+        counts, sub = csr.shard_slot_counts(n0, n1), csr.shard_ee_sub(n0, n1)
+        assert shard.numel() == sum(counts)
+        own = torch.nonzero((dst >= n0) & (dst < n1)).reshape(-1)
+        assert torch.equal(torch.sort(shard).values, own)
+        row = 0
+        for region in range(3):
+            assert torch.equal(shard[row:row + counts[region]] - torch.arange(row, row + counts[region]),
+                               torch.full((counts[region],), sub[region], dtype=torch.long))
+            row += counts[region]
+        c0, c1 = csr.chunk_range(n0, n1)
+        assert c0 == chunks_seen
+        chunks_seen = c1
+        if c1 > c0:
+            hub_slots = shard[counts[0] + counts[1]:]
+            assert int(csr.chunks[c0, 0]) == int(hub_slots[0]) and int(csr.chunks[c1 - 1, 1]) == int(hub_slots[-1]) + 1
+    assert chunks_seen == csr.num_chunks
 
 
 def test_feeder_rejects_bad_input(pkg):
