@@ -70,8 +70,9 @@ const char *mgcn_last_error(void);
  *                                (the three may be NULL when hub_threshold <= 0).
  * Optional outputs for the backward pass (all NULL or all non-NULL):
  *   slot_dst_host [2E] int32     destination node of each slot, bit 31 = half;
- *   srcptr_host [2, N+1] int32, srcslots_host [2E] int32
- *                                per half, the slots (ascending) grouped by SOURCE; srcptr indexes srcslots;
+ *   mirror_host [2E] int32       slot of the reverse edge ((e + E) mod 2E) of each slot's edge: the edges leaving n
+ *                                in half h are the reverses of the edges entering n in half 1-h, so by-SOURCE sums
+ *                                walk the destination runs / hub chunks of the other half through this map;
  *   typeptr_host [num_rel_rows+1] int32, typeslots_host [2E] int32
  *                                all slots (ascending) grouped by relation-table row.
  * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows).
@@ -81,8 +82,8 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
                         int64_t hub_threshold, int64_t hub_chunk, int32_t *rowptr_host,
                         mgcn_edge_rec *rec_host, int64_t *perm_host, int32_t *hubinfo_host,
                         int32_t *chunks_host, int64_t max_chunks, int64_t *num_chunks_host,
-                        int32_t *slot_dst_host, int32_t *srcptr_host, int32_t *srcslots_host,
-                        int32_t *typeptr_host, int32_t *typeslots_host);
+                        int32_t *slot_dst_host, int32_t *mirror_host, int32_t *typeptr_host,
+                        int32_t *typeslots_host);
 
 /* ---------------------------------------------------------------------------------------------
  * (2) Aggregation forward. Replaces the gather / message / scatter-add of the three `propagate`
@@ -120,18 +121,22 @@ int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, i
  *   gx[s]   = sum over slots p with src_p = s of norm_p * g[dst_p, half] * rel[type_p] * ee_p
  *   gee[p]  = norm_p * g[dst_p, half] * x[src_p] * rel[type_p]                 (slot order)
  *   grel[t] = sum over slots p with type_p = t of norm_p * g[dst_p, half] * x[src_p] * ee_p
- * gx walks srcptr/srcslots (slots grouped by source), grel walks typeptr/typeslots (slots grouped by
- * relation row, long lists cut into fixed chunks whose partial sums are added in chunk order); all
- * from mgcn_csr_build_host. Segment sums in a fixed order: no float atomics, bitwise reproducible.
- * Any of gx/gee/grel may be NULL. gx [N, D], gee [2E, D] in slot order, grel [num_rel_rows, D].
+ * gx[s] walks the destination runs of s (rowptr, both halves) and maps every slot to its reverse edge through
+ * `mirror` — within a run that is edge-id order, the order of the CPU index_add; hubs are summed per chunk by a
+ * pre-pass and folded exactly as in (2) (hubinfo / chunks / num_hub_chunks of the whole graph). grel walks
+ * typeptr/typeslots (slots grouped by relation row, long lists cut into fixed chunks whose partial sums are added in
+ * chunk order); all from mgcn_csr_build_host. Sums in a fixed order: no float atomics, bitwise reproducible.
+ * Any of gx/gee/grel may be NULL. gx [N, D], gee [2E, D] in slot order, grel [num_rel_rows, D]. ee_dev is in slot
+ * order. workspace_dev: mgcn_aggregate_bwd_workspace bytes, 16-byte aligned.
  */
 int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
-                       const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev /* bit 31 = half */, const int32_t *srcptr_dev,
-                       const int32_t *srcslots_dev, const int32_t *typeptr_dev, const int32_t *typeslots_dev,
-                       const float *x_dev, int64_t ldx, const float *rel_dev, const float *ee_dev,
+                       const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
+                       const int32_t *slot_dst_dev /* bit 31 = half */, const int32_t *mirror_dev,
+                       const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t num_hub_chunks,
+                       const int32_t *typeptr_dev, const int32_t *typeslots_dev, const float *x_dev, int64_t ldx, const float *rel_dev, const float *ee_dev,
                        const float *g_dev, int64_t ldg, float *gx_dev, float *gee_dev, float *grel_dev,
                        float *workspace_dev, size_t workspace_bytes, void *stream);
-size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows); /* bytes, for grel */
+size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows, int64_t num_hub_chunks);
 
 /* ---------------------------------------------------------------------------------------------
  * (4) Dense step + epilogue (f32 MFMA, exact f32). Replaces model.py:116 (moved after the sum) and

@@ -21,12 +21,12 @@ _SIGNATURES = {
     'mgcn_abi_version': (ctypes.c_int, []),
     'mgcn_last_error': (ctypes.c_char_p, []),
     'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
-                                           _ptr] + [_ptr] * 5),
+                                           _ptr] + [_ptr] * 4),
     'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                           _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
-    'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_ptr, _i64, _ptr, _ptr, _ptr, _i64,
-                                          _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
-    'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
+    'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_i64, _ptr, _ptr] +
+                           [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32, _i64]),
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
@@ -121,14 +121,13 @@ def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward
                chunks=torch.empty((max(max_chunks, 1), 4), dtype=torch.int32))
     nch = ctypes.c_int64(0)
     if with_backward:
-        out.update(slot_dst=torch.empty(E2, dtype=torch.int32), srcptr=torch.empty((2, N + 1), dtype=torch.int32),
-                   srcslots=torch.empty(E2, dtype=torch.int32),
+        out.update(slot_dst=torch.empty(E2, dtype=torch.int32), mirror=torch.empty(E2, dtype=torch.int32),
                    typeptr=torch.empty(num_rel_rows + 1, dtype=torch.int32),
                    typeslots=torch.empty(E2, dtype=torch.int32))
     p = lambda k: out[k].data_ptr() if k in out else None
     _check(lib().mgcn_csr_build_host(N, E, int(num_rel_rows), ei.data_ptr(), et.data_ptr(), thr, chk, p('rowptr'),
                                      p('rec'), p('perm'), p('hubinfo'), p('chunks'), max_chunks, ctypes.byref(nch),
-                                     p('slot_dst'), p('srcptr'), p('srcslots'), p('typeptr'), p('typeslots')),
+                                     p('slot_dst'), p('mirror'), p('typeptr'), p('typeslots')),
            'mgcn_csr_build_host')
     out['num_chunks'] = int(nch.value)
     out['chunks'] = out['chunks'][:max(int(nch.value), 1)].contiguous()
@@ -195,11 +194,15 @@ def aggregate_bwd(csr, x, rel, ee, g, want_gx=True, want_gee=True, want_grel=Tru
     gx = torch.empty((N, D), dtype=torch.float32, device=x.device) if want_gx else None
     gee = torch.empty((2 * E, D), dtype=torch.float32, device=x.device) if (want_gee and ee is not None) else None
     grel = torch.empty((csr.num_rel_rows, D), dtype=torch.float32, device=x.device) if want_grel else None
-    ws_bytes = lib().mgcn_aggregate_bwd_workspace(E, D, csr.num_rel_rows) if want_grel else 0
-    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device) if want_grel else None
+    need_ws = want_grel or (want_gx and csr.num_chunks > 0)
+    ws_bytes = lib().mgcn_aggregate_bwd_workspace(E, D, csr.num_rel_rows, csr.num_chunks) if need_ws else 0
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device) if need_ws else None
+    hubs = csr.num_chunks > 0
     _check(lib().mgcn_aggregate_bwd(
-        N, E, D, csr.num_rel_rows, _dev(csr.rec, torch.int32, 'rec'), _dev(csr.slot_dst, torch.int32, 'slot_dst'),
-        _dev(csr.srcptr, torch.int32, 'srcptr'), _dev(csr.srcslots, torch.int32, 'srcslots'),
+        N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
+        _dev(csr.slot_dst, torch.int32, 'slot_dst'), _dev(csr.mirror, torch.int32, 'mirror'),
+        _dev(csr.hubinfo, torch.int32, 'hubinfo') if hubs else None,
+        _dev(csr.chunks, torch.int32, 'chunks') if hubs else None, csr.num_chunks,
         _dev(csr.typeptr, torch.int32, 'typeptr'), _dev(csr.typeslots, torch.int32, 'typeslots'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(ee, torch.float32, 'ee', True),
         _dev(g, torch.float32, 'g'), _ld(g), _dev(gx, torch.float32, 'gx', True), _dev(gee, torch.float32, 'gee', True),

@@ -213,8 +213,14 @@ __global__ __launch_bounds__(256) void agg_hub_kernel(AggArgs p, int gs_log2) {
 // Hub fold: the workgroup of a hub's FIRST chunk adds the hub's chunk sums into that chunk's row (all other
 // workgroups leave at once). Lane group j adds chunks j, j+J, j+2J, ... in that order (U loads in flight), then
 // group 0 adds the J group sums in group order: a fixed summation tree, so results are reproducible.
+struct FoldArgs {
+  const int4 *chunks;
+  float *partial;
+  int32_t chunk0, d;
+};
+
 template <int VEC, int CPL>
-__global__ __launch_bounds__(256) void agg_hub_fold_kernel(AggArgs p, int gs_log2) {
+__global__ __launch_bounds__(256) void agg_hub_fold_kernel(FoldArgs p, int gs_log2) {
   using V = Vec<VEC>;
   using T = typename V::type;
   extern __shared__ float red[];  // [J][D]
@@ -274,8 +280,12 @@ __global__ __launch_bounds__(256) void agg_hub_fold_kernel(AggArgs p, int gs_log
 struct BwdArgs {
   const int4 *rec;
   const int32_t *slot_dst;
-  const int32_t *srcptr;     // [2][N+1]
-  const int32_t *srcslots;   // [2E]
+  const int32_t *rowptr;     // [2][N+1] destination runs (absolute slots)
+  const int32_t *mirror;     // [2E] slot -> slot of the reverse edge
+  const int2 *hubinfo;       // [2][N] or null
+  const int4 *chunks;        // hub chunks of the whole graph
+  float *hub_ws;             // [nchunks_hub][D] chunk sums of gx
+  int32_t nchunks_hub;
   const int32_t *typeptr;    // [T+1]
   const int32_t *typeslots;  // [2E]
   const float *x, *rel, *ee, *g;
@@ -313,7 +323,65 @@ __global__ __launch_bounds__(256) void agg_bwd_gee_kernel(BwdArgs p, int gs_log2
   }
 }
 
-// gx[node] = sum over both halves' by-source lists of (g[dst, half] * norm) * rel[type] * ee[slot].
+// By-source sums through the mirror map: the edges that leave `node` in half hq are the reverses of the slots p that
+// enter it in half 1-hq; reverse slot q = mirror[p] has dst_q = src_p. Contribution of q:
+// ((g[dst_q, hq] * norm_q) * rel[type_q]) * ee[q]. U slots per batch: indices, then reverse records, then 3*U rows.
+template <int VEC, int CPL>
+__device__ __forceinline__ void gx_walk(const BwdArgs &p, int beg, int end, int hq, int lig, int gs,
+                                        typename Vec<VEC>::type (&acc)[CPL]) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  constexpr int U = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);
+  const int nchunk = p.d / VEC;
+  const int32_t *src_of = reinterpret_cast<const int32_t *>(p.rec);   // rec[s].src = word 4*s
+  for (int s = beg; s < end; s += U) {
+    int dq[U], q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s + u < end) {
+        dq[u] = src_of[4 * int64_t(s + u)];
+        q[u] = p.mirror[s + u];
+      }
+    int4 rq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (s + u < end) rq[u] = p.rec[q[u]];
+    T gv[U][CPL], rv[U][CPL], ev[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u >= end) continue;
+      const float *gr = p.g + int64_t(dq[u]) * p.ldg + hq * p.d;
+      const float *rr = p.rel + int64_t(rq[u].y) * p.d;
+      const float *er = p.ee ? p.ee + int64_t(q[u]) * p.d : nullptr;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) {
+          gv[u][c] = V::load(gr + ch * VEC);
+          rv[u][c] = V::load(rr + ch * VEC);
+          if (er) ev[u][c] = V::load(er + ch * VEC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (s + u >= end) continue;
+      const float w = __int_as_float(rq[u].z);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) {
+          T m = V::mul(V::muls(gv[u][c], w), rv[u][c]);
+          if (p.ee) m = V::mul(m, ev[u][c]);
+          acc[c] = V::add(acc[c], m);
+        }
+      }
+    }
+  }
+}
+
+// gx[node]: reverse edges in half 0 (destination run of half 1), then half 1; a hub's run is empty and its folded
+// chunk sums are added instead.
 template <int VEC, int CPL>
 __global__ __launch_bounds__(256) void agg_bwd_gx_kernel(BwdArgs p, int gs_log2) {
   using V = Vec<VEC>;
@@ -326,23 +394,17 @@ __global__ __launch_bounds__(256) void agg_bwd_gx_kernel(BwdArgs p, int gs_log2)
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-  for (int half = 0; half < 2; ++half) {
-    const int32_t *sp = p.srcptr + int64_t(half) * (p.n + 1);
-    const int beg = sp[node], end = sp[node + 1];
-    for (int i = beg; i < end; ++i) {
-      const int slot = p.srcslots[i];
-      const int4 r = p.rec[slot];
-      const float w = __int_as_float(r.z);
-      const float *gr = p.g + int64_t(p.slot_dst[slot] & 0x7fffffff) * p.ldg + half * p.d;
-      const float *rr = p.rel + int64_t(r.y) * p.d;
-      const float *er = p.ee ? p.ee + int64_t(slot) * p.d : nullptr;
+  for (int hq = 0; hq < 2; ++hq) {
+    const int h = 1 - hq;
+    const int32_t *rp = p.rowptr + int64_t(h) * (p.n + 1);
+    gx_walk<VEC, CPL>(p, rp[node], rp[node + 1], hq, lig, gs, acc);
+    if (p.hubinfo) {
+      const int2 hi = p.hubinfo[int64_t(h) * p.n + node];
+      if (hi.y > 0) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int ch = lig + c * gs;
-        if (ch < nchunk) {
-          T m = V::mul(V::muls(V::load(gr + ch * VEC), w), V::load(rr + ch * VEC));
-          if (er) m = V::mul(m, V::load(er + ch * VEC));
-          acc[c] = V::add(acc[c], m);
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = lig + c * gs;
+          if (ch < nchunk) acc[c] = V::add(acc[c], V::load(p.hub_ws + int64_t(hi.x) * p.d + ch * VEC));
         }
       }
     }
@@ -351,6 +413,29 @@ __global__ __launch_bounds__(256) void agg_bwd_gx_kernel(BwdArgs p, int gs_log2)
   for (int c = 0; c < CPL; ++c) {
     const int ch = lig + c * gs;
     if (ch < nchunk) V::store(p.gx + node * p.d + ch * VEC, acc[c]);
+  }
+}
+
+// Hub pre-pass of gx: one lane group per hub chunk (then agg_hub_fold_kernel).
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_gx_hub_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t chunk = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (chunk >= p.nchunks_hub) return;
+  const int nchunk = p.d / VEC;
+  const int4 range = p.chunks[chunk];
+  const int hq = 1 - ((p.slot_dst[range.x] >> 31) & 1);   // the chunk's slots enter the hub in half 1-hq
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  gx_walk<VEC, CPL>(p, range.x, range.y, hq, lig, gs, acc);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) V::store(p.hub_ws + chunk * p.d + ch * VEC, acc[c]);
   }
 }
 
@@ -474,6 +559,29 @@ bool pick_geometry(int d, bool all_aligned, Geometry *g) {
     }                                                                                                     \
   } while (0)
 
+void launch_fold(const Geometry &g, const int4 *chunks, float *partial, int32_t chunk0, int32_t dim, int64_t num_chunks,
+                 hipStream_t st) {
+  FoldArgs f = {chunks, partial, chunk0, dim};
+  const size_t lds = size_t(256 >> g.gs_log2) * size_t(dim) * sizeof(float);
+#define MGCN_FOLD_CASE(V_, C_) hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, f, g.gs_log2)
+  if (g.vec == 4) {
+    switch (g.cpl) {
+      case 1: MGCN_FOLD_CASE(4, 1); break;
+      case 2: MGCN_FOLD_CASE(4, 2); break;
+      case 4: MGCN_FOLD_CASE(4, 4); break;
+      default: MGCN_FOLD_CASE(4, 8); break;
+    }
+  } else {
+    switch (g.cpl) {
+      case 1: MGCN_FOLD_CASE(1, 1); break;
+      case 2: MGCN_FOLD_CASE(1, 2); break;
+      case 4: MGCN_FOLD_CASE(1, 4); break;
+      default: MGCN_FOLD_CASE(1, 8); break;
+    }
+  }
+#undef MGCN_FOLD_CASE
+}
+
 }  // namespace
 
 int mgcn::launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_rows, const mgcn_edge_rec *rec_dev,
@@ -516,24 +624,7 @@ int mgcn::launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_ro
   }
 #undef MGCN_HUB_CASE
   MGCN_CHECK_LAUNCH("agg_hub_kernel");
-  const size_t lds = size_t(256 >> g.gs_log2) * size_t(dim) * sizeof(float);
-#define MGCN_FOLD_CASE(V_, C_) hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, p, g.gs_log2)
-  if (g.vec == 4) {
-    switch (g.cpl) {
-      case 1: MGCN_FOLD_CASE(4, 1); break;
-      case 2: MGCN_FOLD_CASE(4, 2); break;
-      case 4: MGCN_FOLD_CASE(4, 4); break;
-      default: MGCN_FOLD_CASE(4, 8); break;
-    }
-  } else {
-    switch (g.cpl) {
-      case 1: MGCN_FOLD_CASE(1, 1); break;
-      case 2: MGCN_FOLD_CASE(1, 2); break;
-      case 4: MGCN_FOLD_CASE(1, 4); break;
-      default: MGCN_FOLD_CASE(1, 8); break;
-    }
-  }
-#undef MGCN_FOLD_CASE
+  launch_fold(g, p.chunks, p.partial, p.chunk0, dim, num_chunks, st);
   MGCN_CHECK_LAUNCH("agg_hub_fold_kernel");
   return MGCN_OK;
 }
@@ -620,14 +711,16 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   return MGCN_OK;
 }
 
-extern "C" size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows) {
+extern "C" size_t mgcn_aggregate_bwd_workspace(int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
+                                               int64_t num_hub_chunks) {
   const int64_t nchunks = (2 * num_edges_half + kTypeChunk - 1) / kTypeChunk;
-  return size_t(nchunks + num_rel_rows) * size_t(dim) * sizeof(float);
+  return size_t(nchunks + num_rel_rows + (num_hub_chunks > 0 ? num_hub_chunks : 0)) * size_t(dim) * sizeof(float);
 }
 
 extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
-                                  const mgcn_edge_rec *rec_dev, const int32_t *slot_dst_dev,
-                                  const int32_t *srcptr_dev, const int32_t *srcslots_dev,
+                                  const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
+                                  const int32_t *slot_dst_dev, const int32_t *mirror_dev,
+                                  const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t num_hub_chunks,
                                   const int32_t *typeptr_dev, const int32_t *typeslots_dev, const float *x_dev,
                                   int64_t ldx, const float *rel_dev, const float *ee_dev, const float *g_dev,
                                   int64_t ldg, float *gx_dev, float *gee_dev, float *grel_dev,
@@ -638,7 +731,13 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
   MGCN_REQUIRE(x_dev && rel_dev && g_dev, "aggregate_bwd: null pointer");
   MGCN_REQUIRE(num_edges_half == 0 || (rec_dev && slot_dst_dev), "aggregate_bwd: null slot arrays");
   MGCN_REQUIRE(ldx >= dim && ldg >= 2 * int64_t(dim), "aggregate_bwd: ldx/ldg too small");
-  MGCN_REQUIRE(!gx_dev || (srcptr_dev && (num_edges_half == 0 || srcslots_dev)), "aggregate_bwd: gx needs srcptr/srcslots");
+  MGCN_REQUIRE(!gx_dev || (rowptr_dev && (num_edges_half == 0 || mirror_dev)), "aggregate_bwd: gx needs rowptr/mirror");
+  MGCN_REQUIRE(num_hub_chunks >= 0 && num_hub_chunks < (int64_t(1) << 31) &&
+                   (num_hub_chunks == 0 || !gx_dev || (hubinfo_dev && chunks_dev)),
+               "aggregate_bwd: hub chunks need hubinfo / chunks");
+  const size_t ws_need = mgcn_aggregate_bwd_workspace(num_edges_half, dim, num_rel_rows, num_hub_chunks);
+  MGCN_REQUIRE(!(grel_dev || (gx_dev && num_hub_chunks > 0)) || (workspace_dev && workspace_bytes >= ws_need),
+               "aggregate_bwd: workspace too small (%zu bytes needed)", ws_need);
   MGCN_REQUIRE(!grel_dev || (typeptr_dev && (num_edges_half == 0 || typeslots_dev)), "aggregate_bwd: grel needs typeptr/typeslots");
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(g_dev) &&
                        (!ee_dev || mgcn::aligned16(ee_dev)) && (!gx_dev || mgcn::aligned16(gx_dev)) &&
@@ -649,8 +748,11 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
   BwdArgs p;
   p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.slot_dst = slot_dst_dev;
-  p.srcptr = srcptr_dev;
-  p.srcslots = srcslots_dev;
+  p.rowptr = rowptr_dev;
+  p.mirror = mirror_dev;
+  p.hubinfo = num_hub_chunks > 0 ? reinterpret_cast<const int2 *>(hubinfo_dev) : nullptr;
+  p.chunks = reinterpret_cast<const int4 *>(chunks_dev);
+  p.nchunks_hub = int32_t(num_hub_chunks);
   p.typeptr = typeptr_dev;
   p.typeslots = typeslots_dev;
   p.x = x_dev;
@@ -668,17 +770,22 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
   p.d = dim;
   p.rel_rows = num_rel_rows;
   p.nchunks_type = int32_t((2 * num_edges_half + kTypeChunk - 1) / kTypeChunk);
+  p.hub_ws = workspace_dev ? workspace_dev + (int64_t(p.nchunks_type) + num_rel_rows) * dim : nullptr;
   if (gee_dev && num_edges_half > 0) {
     MGCN_LAUNCH_GEOM(agg_bwd_gee_kernel, p, 2 * num_edges_half, g, stream);
     MGCN_CHECK_LAUNCH("agg_bwd_gee_kernel");
   }
   if (gx_dev && num_nodes > 0) {
+    if (num_hub_chunks > 0) {
+      MGCN_LAUNCH_GEOM(agg_bwd_gx_hub_kernel, p, num_hub_chunks, g, stream);
+      MGCN_CHECK_LAUNCH("agg_bwd_gx_hub_kernel");
+      launch_fold(g, p.chunks, p.hub_ws, 0, dim, num_hub_chunks, static_cast<hipStream_t>(stream));
+      MGCN_CHECK_LAUNCH("agg_hub_fold_kernel");
+    }
     MGCN_LAUNCH_GEOM(agg_bwd_gx_kernel, p, num_nodes, g, stream);
     MGCN_CHECK_LAUNCH("agg_bwd_gx_kernel");
   }
   if (grel_dev) {
-    MGCN_REQUIRE(workspace_dev && workspace_bytes >= mgcn_aggregate_bwd_workspace(num_edges_half, dim, num_rel_rows),
-                 "aggregate_bwd: workspace too small");
     if (p.nchunks_type > 0) {
       MGCN_LAUNCH_GEOM(agg_bwd_grel_partial_kernel, p, p.nchunks_type, g, stream);
       MGCN_CHECK_LAUNCH("agg_bwd_grel_partial_kernel");

@@ -23,8 +23,8 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
                                    int64_t hub_threshold, int64_t hub_chunk, int32_t *rowptr_host,
                                    mgcn_edge_rec *rec_host, int64_t *perm_host, int32_t *hubinfo_host,
                                    int32_t *chunks_host, int64_t max_chunks, int64_t *num_chunks_host,
-                                   int32_t *slot_dst_host, int32_t *srcptr_host, int32_t *srcslots_host,
-                                   int32_t *typeptr_host, int32_t *typeslots_host) {
+                                   int32_t *slot_dst_host, int32_t *mirror_host, int32_t *typeptr_host,
+                                   int32_t *typeslots_host) {
   const int64_t N = num_nodes, E = num_edges_half, E2 = 2 * num_edges_half;
   MGCN_REQUIRE(N >= 0 && E >= 0 && num_rel_rows >= 0, "csr_build: negative size");
   MGCN_REQUIRE(N < (int64_t(1) << 31) - 1 && E2 < (int64_t(1) << 31) - 1, "csr_build: sizes exceed int32 slots");
@@ -33,10 +33,9 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
   const bool hubs = hub_threshold > 0;
   MGCN_REQUIRE(!hubs || (hub_chunk > 0 && hubinfo_host && chunks_host && num_chunks_host),
                "csr_build: hub splitting needs hub_chunk > 0 and the hubinfo / chunks / num_chunks outputs");
-  const bool bwd = srcptr_host != nullptr;
-  MGCN_REQUIRE(bwd == (typeptr_host != nullptr) &&
-                   (E == 0 || (bwd == (slot_dst_host != nullptr) && bwd == (srcslots_host != nullptr) &&
-                               bwd == (typeslots_host != nullptr))),
+  const bool bwd = typeptr_host != nullptr;
+  MGCN_REQUIRE(E == 0 || (bwd == (slot_dst_host != nullptr) && bwd == (mirror_host != nullptr) &&
+                          bwd == (typeslots_host != nullptr)),
                "csr_build: backward index outputs must be given all together or not at all");
   const int64_t *src = edge_index_host, *dst = edge_index_host + E2;
   for (int64_t e = 0; e < E2; ++e) {
@@ -111,21 +110,12 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
     }
   }
   if (bwd) {
-    // slots grouped by (half, source), ascending slot id; srcptr positions index srcslots directly
-    std::vector<int32_t> scount(2 * N, 0);
-    for (int64_t s = 0; s < E2; ++s) scount[((slot_dst_host[s] >> 31) & 1) * N + rec_host[s].src]++;
-    int64_t sp = 0;
-    for (int h = 0; h < 2; ++h) {
-      for (int64_t n = 0; n < N; ++n) {
-        srcptr_host[h * (N + 1) + n] = int32_t(sp);
-        sp += scount[h * N + n];
-      }
-      srcptr_host[h * (N + 1) + N] = int32_t(sp);
-    }
-    std::vector<int32_t> sc(2 * N);
-    for (int h = 0; h < 2; ++h)
-      for (int64_t n = 0; n < N; ++n) sc[h * N + n] = srcptr_host[h * (N + 1) + n];
-    for (int64_t s = 0; s < E2; ++s) srcslots_host[sc[((slot_dst_host[s] >> 31) & 1) * N + rec_host[s].src]++] = int32_t(s);
+    // mirror: slot of edge e <-> slot of its reverse edge (e + E) mod 2E. The edges that LEAVE node n in half h are
+    // the reverses of the edges that ENTER n in half 1-h, so the by-source sums of the backward walk the same
+    // destination runs (and hub chunks) as the forward, through this map.
+    std::vector<int32_t> slot_of(E2);
+    for (int64_t s = 0; s < E2; ++s) slot_of[perm_host[s]] = int32_t(s);
+    for (int64_t s = 0; s < E2; ++s) mirror_host[s] = slot_of[(perm_host[s] + E) % E2];
     // all slots grouped by relation row, ascending slot id
     std::vector<int32_t> tcur(num_rel_rows + 1, 0);
     std::memset(typeptr_host, 0, sizeof(int32_t) * (num_rel_rows + 1));

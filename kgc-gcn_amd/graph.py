@@ -13,7 +13,7 @@ from . import _native
 class GraphCSR(object):
     """Device-resident slot arrays produced by mgcn_csr_build_host (include/mgcn_hip.h (1))."""
 
-    _FIELDS = ('rowptr', 'rec', 'perm', 'hubinfo', 'chunks', 'slot_dst', 'srcptr', 'srcslots', 'typeptr', 'typeslots')
+    _FIELDS = ('rowptr', 'rec', 'perm', 'hubinfo', 'chunks', 'slot_dst', 'mirror', 'typeptr', 'typeslots')
 
     def __init__(self, num_nodes, num_rel_rows, edge_index, edge_type, device, with_backward=True, hub_threshold=None,
                  hub_chunk=None):

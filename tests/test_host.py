@@ -40,9 +40,9 @@ def test_feeder_bit_exact(pkg, case):
         assert np.array_equal(h['rec'][lo:lo + E, 3].numpy(), order)
         sd = h['slot_dst'][lo:lo + E].numpy()
         assert np.array_equal(sd & 0x7fffffff, dst[order - lo]) and bool((((sd >> 31) & 1) == half).all())
-        src_of_slot = h['rec'][lo:lo + E, 0].numpy()
-        assert np.array_equal(h['srcslots'][lo:lo + E].numpy(), np.argsort(src_of_slot, kind='stable') + lo)
-        assert np.array_equal(h['srcptr'][half].numpy(), lo + np.concatenate([[0], np.cumsum(np.bincount(src_of_slot, minlength=N))]))
+    perm, mirror = h['perm'].numpy(), h['mirror'].numpy()
+    assert np.array_equal(perm[mirror], (perm + E) % (2 * E))              # slot of the reverse edge
+    assert np.array_equal(h['rec'][:, 0].numpy()[mirror], h['slot_dst'].numpy() & 0x7fffffff)   # src of reverse = dst
     typ = h['rec'][:, 1].numpy()
     assert np.array_equal(h['typeslots'].numpy(), np.argsort(typ, kind='stable'))
     assert np.array_equal(h['typeptr'].numpy(), np.concatenate([[0], np.cumsum(np.bincount(typ, minlength=2 * R + 1))]))

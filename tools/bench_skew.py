@@ -17,7 +17,7 @@ def graph(zipf, seed=0):
         o = rng.integers(0, N, E)
     ei = torch.from_numpy(np.stack((np.concatenate((s, o)), np.concatenate((o, s)))))
     et = torch.from_numpy(np.concatenate((r, r + R)))
-    return pkg.GraphCSR(N, 2 * R + 1, ei, et, dev, with_backward=False)
+    return pkg.GraphCSR(N, 2 * R + 1, ei, et, dev, with_backward=True)
 torch.manual_seed(0)
 conv = pkg.MGCNConv(D, O, 2 * R).to(dev).eval()
 x = torch.randn(N, D, device=dev) * 0.1; rel = torch.randn(2 * R, D, device=dev) * 0.3; ee = torch.randn(2 * E, D, device=dev)
@@ -40,4 +40,13 @@ for zipf in (0.0, 0.8, 1.1, 1.4):
     c.record()
     for _ in range(50): fn2()
     d.record(); torch.cuda.synchronize()
-    print('zipf %.1f  max in/out degree %6d  fused layer %7.1f us   aggregate-only launch %7.1f us' % (zipf, deg, a.elapsed_time(b) / 50 * 1e3, c.elapsed_time(d) / 50 * 1e3))
+    gA = torch.randn(N, 3 * D, device=dev)
+    relfull = torch.cat([rel, conv.loop_rel.detach().reshape(1, -1)])
+    fn3 = lambda: nat.aggregate_bwd(csr, x, relfull, ee, gA)
+    fn3(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fn3()
+    e1.record(); torch.cuda.synchronize()
+    print('zipf %.1f  max run %5d  hub chunks %6d  fused layer %7.1f us   aggregate-only %7.1f us   backward (gx+gee+grel) %8.1f us'
+          % (zipf, deg, csr.num_chunks, a.elapsed_time(b) / 50 * 1e3, c.elapsed_time(d) / 50 * 1e3, e0.elapsed_time(e1) / 20 * 1e3))
