@@ -11,9 +11,12 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 32, KS = 16;
 
+// tanh(v) = sign(v) (1 - t) / (1 + t), t = exp(-2|v|), with the hardware exp2 and reciprocal (1 ulp each): this
+// kernel is bound by the SIMD's vector issue (VALU work does not overlap v_mfma_f32_16x16x4_f32 issue — measured,
+// tools/mfma_coexec.hip), so the epilogue is written for instruction count: 7 VALU per value instead of ~20.
 __device__ __forceinline__ float tanhf_(float v) {
-  const float t = __expf(-2.0f * fabsf(v));
-  return copysignf((1.0f - t) / (1.0f + t), v);
+  const float t = __builtin_amdgcn_exp2f(fabsf(v) * -2.885390081777927f);   // exp(-2|v|) = 2^(-2 log2(e) |v|)
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
 }
 
 int pick_nt(int64_t ncols) { return ncols <= 32 ? 2 : ncols <= 64 ? 4 : ncols <= 128 ? 8 : 13; }
@@ -70,6 +73,35 @@ __global__ __launch_bounds__(256) void pack_w_kernel(const float *__restrict__ w
 
 constexpr int FUSED_THREADS = 512;
 
+// Epilogue + row stores of a finished tile: /3, bias, BN(eval), tanh (model.py:103-106) on the raw accumulators the
+// MFMA waves left in the LDS staging tile `Os`. Run by the 256 GATHER threads (their VALU idles on memory latency,
+// while the MFMA waves' time is the kernel's critical path): thread -> one fixed float4 column, rows frow0,
+// frow0 + rstep, ... Kept out of line so that its registers do not add to the gather loops' pressure.
+__device__ __forceinline__ void finalize_tile(const FusedArgs &p, const float *Os, int ldo_s, int pr0, int gtid) {
+  const int c4n = p.o >> 2;
+  const int frow0 = gtid / c4n, fcol = (gtid - frow0 * c4n) * 4, rstep = 256 / c4n;
+  if (frow0 >= rstep) return;
+  const float4 mean = *reinterpret_cast<const float4 *>(p.bn_mean + fcol);
+  const float4 var = *reinterpret_cast<const float4 *>(p.bn_var + fcol);
+  const float4 gam = *reinterpret_cast<const float4 *>(p.bn_gamma + fcol);
+  const float4 bet = *reinterpret_cast<const float4 *>(p.bn_beta + fcol);
+  const float4 cb = p.bias ? *reinterpret_cast<const float4 *>(p.bias + fcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 inv = make_float4(1.0f / sqrtf(var.x + p.bn_eps), 1.0f / sqrtf(var.y + p.bn_eps),
+                                 1.0f / sqrtf(var.z + p.bn_eps), 1.0f / sqrtf(var.w + p.bn_eps));
+  for (int lrow = frow0; lrow < BM; lrow += rstep) {
+    if (pr0 + lrow >= p.node1 - p.node0) break;
+    float4 v = *reinterpret_cast<const float4 *>(Os + lrow * ldo_s + fcol);
+    if (!(p.ablate & 8)) {
+      constexpr float third = 1.0f / 3.0f;   // (sum of the three modes) / 3, model.py:103, as a multiplication (<= 1 ulp)
+      v = make_float4(v.x * third, v.y * third, v.z * third, v.w * third);
+      if (p.bias) v = make_float4(v.x + cb.x, v.y + cb.y, v.z + cb.z, v.w + cb.w);
+      v = make_float4(tanhf_((v.x - mean.x) * inv.x * gam.x + bet.x), tanhf_((v.y - mean.y) * inv.y * gam.y + bet.y),
+                      tanhf_((v.z - mean.z) * inv.z * gam.z + bet.z), tanhf_((v.w - mean.w) * inv.w * gam.w + bet.w));
+    }
+    *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + fcol) = v;
+  }
+}
+
 // PERSISTENT: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the gather -> multiply pipeline runs
 // straight across tile boundaries: stage s = 3*tile + mode; while the MFMA waves multiply stage s the gather waves
 // fetch stage s + 1 (the next tile's in-half when s is a self-loop stage). One workgroup barrier per stage. A
@@ -103,21 +135,45 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     const int g_lo = grp * rpg, g_hi = g_lo + rpg;
     const bool col_ok = lig * 4 < p.d;
     const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
+    auto finalize = [&](int tile_it) {
+      if (!(p.ablate & 4)) finalize_tile(p, Os, LDO, (int(blockIdx.x) + tile_it * int(gridDim.x)) * BM, gtid);
+    };
+    // A stage's memory chain is row pointers -> slot records -> rows. The first two links are fetched ONE STAGE
+    // AHEAD: lane i of a group holds the row pointer of destination g_lo + i and the record of slot beg + i (the
+    // group's slots are one contiguous range), so a stage starts straight at its row loads and the records reach the
+    // whole group through ds_bpermute. Runs longer than the group (hub-free runs are <= 64 slots per destination)
+    // reload the record chunk on demand.
+    auto rp_of = [&](int it_, int mode_) {
+      int node = p.node0 + (int(blockIdx.x) + it_ * int(gridDim.x)) * BM + g_lo + (lig <= rpg ? lig : rpg);
+      node = node < p.node1 ? node : p.node1;
+      return p.rowptr[int64_t(mode_) * (p.n + 1) + node];   // absolute slot position
+    };
+    auto rec_chunk = [&](int cbeg, int end) {   // lane i: record of slot cbeg + i (clamped to the range's last slot)
+      int4 r = make_int4(0, 0, 0, 0);
+      if (end > cbeg) r = p.rec[(cbeg + lig < end) ? cbeg + lig : end - 1];
+      return r;
+    };
+    int currp = (p.ablate & 1) ? 0 : rp_of(0, 0);
+    int4 currec = rec_chunk(__shfl(currp, glane0), __shfl(currp, glane0 + rpg));
     int stage = 0;
     for (int it = 0; it < my_tiles; ++it) {
       const int r0 = p.node0 + (int(blockIdx.x) + it * int(gridDim.x)) * BM;
       for (int mode = 0; mode < 3; ++mode, ++stage) {
         float *at = As + (stage & 1) * BM * lda;
+        if (mode == 2 && it > 0) finalize(it - 1);   // Os holds tile it-1 since the barrier two stages back
         if (p.ablate & 1) {
         } else if (mode < 2) {
-          // the group's rpg + 1 row pointers: lane i of the group holds the pointer of destination g_lo + i
+          const int myrp = currp;
+          int4 myrec = currec;
+          const bool has_next = mode == 0 || it + 1 < my_tiles;   // next stage with records: (it, 1) or (it + 1, 0)
+          int nrp = 0;
+          if (has_next) nrp = rp_of(mode == 0 ? it : it + 1, mode == 0 ? 1 : 0);
+          bool next_recs_issued = false;
+          int4 nrec = make_int4(0, 0, 0, 0);
           int node = r0 + g_lo + (lig <= rpg ? lig : rpg);
-          node = node < p.node1 ? node : p.node1;
-          const int myrp = p.rowptr[int64_t(mode) * (p.n + 1) + node];   // absolute slot position
           int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination g_lo + i
           if (p.hubinfo && lig < rpg && node < p.node1) myhub = p.hubinfo[int64_t(mode) * p.n + node];
-          const int64_t base = 0;
-          const int end = __shfl(myrp, glane0 + rpg);
+          const int beg = __shfl(myrp, glane0), end = __shfl(myrp, glane0 + rpg);
           int row = g_lo, nb = __shfl(myrp, glane0 + 1);
           float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
           auto add_hub = [&](int r) {   // a hub's own run is empty: its total sits in the row of its first chunk (group-uniform)
@@ -128,20 +184,35 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
               sum = make_float4(sum.x + ps.x, sum.y + ps.y, sum.z + ps.z, sum.w + ps.w);
             }
           };
-          for (int s = __shfl(myrp, glane0); s < end; s += U) {
-            int4 r[U];
+          int cbase = beg;                                   // first slot of the record chunk held in myrec
+          for (int s = beg; s < end; s += U) {
+            if (s >= cbase + gs) {                           // group-uniform: next chunk of a long range
+              cbase += gs;
+              myrec = rec_chunk(cbase, end);
+            }
+            int rsrc[U], rtyp[U], rnrm[U], reid[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) r[u] = p.rec[base + ((s + u < end) ? s + u : end - 1)];
+            for (int u = 0; u < U; ++u) {
+              const int from = glane0 + (((s + u < end) ? s + u : end - 1) - cbase);
+              rsrc[u] = __shfl(myrec.x, from);
+              rtyp[u] = __shfl(myrec.y, from);
+              rnrm[u] = __shfl(myrec.z, from);
+              if (p.ee && !p.ee_slot_order) reid[u] = __shfl(myrec.w, from);
+            }
             float4 xv[U], rv[U], ev[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(r[u].x) * p.ldx + coff);
-              const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
+              xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(rsrc[u]) * p.ldx + coff);
+              const float *rr = (rtyp[u] < p.rel_rows - 1) ? p.rel + int64_t(rtyp[u]) * p.d : p.loop_rel;
               rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
               if (p.ee) {
-                const int64_t slot = base + ((s + u < end) ? s + u : end - 1);
-                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot - p.ee_sub[mode] : int64_t(r[u].w)) * p.d + coff);
+                const int64_t slot = (s + u < end) ? s + u : end - 1;
+                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot - p.ee_sub[mode] : int64_t(reid[u])) * p.d + coff);
               }
+            }
+            if (!next_recs_issued) {   // behind this batch's row loads: the next stage's records (its row pointers are back)
+              next_recs_issued = true;
+              if (has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + rpg));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -159,11 +230,14 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
                 }
                 float4 m = f4mul(xv[u], rv[u]);
                 if (p.ee) m = f4mul(m, ev[u]);
-                const float wgt = __int_as_float(r[u].z);
+                const float wgt = __int_as_float(rnrm[u]);
                 sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
               }
             }
           }
+          if (!next_recs_issued && has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + rpg));
+          currp = nrp;
+          currec = nrec;
           for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
             add_hub(row);
             if (col_ok) {
@@ -189,21 +263,28 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
         __syncthreads();  // end of stage: As[stage & 1] is complete
       }
     }
-    __syncthreads();      // the drain stage (the MFMA waves multiply the last mode)
+    __syncthreads();      // the drain stage (the MFMA waves multiply the last mode and leave its accumulators in Os)
+    finalize(my_tiles - 1);
   } else {
-    // MFMA wave w owns BOTH 16-row tiles of the block and a contiguous run of column tiles (4, 3, 3, 3 of the 13
-    // for O = 200): a weight fragment is loaded once per block (not once per row tile) and feeds two MFMAs, and
-    // only NTW fragments per k-block are needed, so they can be prefetched THREE k-blocks ahead in registers —
-    // the fragments come from L2 and one k-block of MFMAs (~0.4 us) does not cover that latency.
-    const int q4 = NT / 4, r4 = NT % 4;
-    const int wsel = wave;
-    const int ct0 = wsel * q4 + (wsel < r4 ? wsel : r4);
-    const int nct = q4 + (wsel < r4 ? 1 : 0);
+    // The block's work per stage is 2 x NT (row tile, column tile) units. Every MFMA wave owns Q4 = NT/4 column tiles
+    // with BOTH 16-row tiles (a weight fragment feeds two MFMAs), and the NT%4 left-over column tiles are shared out
+    // as single units: NT = 13 -> waves 0,1 take row tile 0 / 1 of the 13th column tile (7,7,6,6 units instead of
+    // 8,6,6,6); NT = 2 -> every wave takes one unit. Co-resident blocks (b, b+256 with two blocks per CU) swap the
+    // wave pairs so that each SIMD's MFMA pipe sees 13 units per stage pair. Only NTW fragments per k-block are
+    // needed, so they are prefetched THREE k-blocks ahead in registers — they come from L2 and one k-block of MFMAs
+    // (~0.4 us) does not cover that latency.
+    constexpr int Q4 = NT / 4, R4 = NT % 4;
+    static_assert(R4 != 3, "column tile counts with NT % 4 == 3 are not instantiated");
+    constexpr int QF = Q4 > 0 ? Q4 : 1;            // array extent for the full tiles (Q4 may be 0)
+    const int wsel = wave ^ ((int(blockIdx.x >> 8) & 1) << 1);
+    const int ct0 = wsel * Q4;
+    const bool has_half = R4 == 2 || (R4 == 1 && wsel < 2);
+    const int hct = 4 * Q4 + (R4 == 2 ? (wsel >> 1) : 0);   // the shared column tile of this wave's single unit
+    const bool hrt = (wsel & 1) != 0;                        // ... and its row tile
     const int fr = lane & 15, fq = lane >> 4;
-    const int c4n = p.o >> 2;
     const int nkb3 = 3 * nkb;                      // k-blocks per tile over the three modes
-    auto wload = [&](int g, int t) {               // fragment of k-block g (0 .. nkb3-1, mode-major), column tile t
-      const int ct = (t < nct) ? ct0 + t : ct0;
+    auto wload = [&](int g, int t) {               // fragment of k-block g (0 .. nkb3-1, mode-major), register slot t
+      const int ct = (t < Q4) ? ct0 + t : (has_half ? hct : 0);
       return p.wp[(int64_t(g) * NT + ct) * 64 + lane];
     };
     float4 w0[NTW], w1[NTW], w2[NTW];
@@ -214,88 +295,85 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
       w2[t] = wload(2 % nkb3, t);
     }
     __syncthreads();      // stage 0 (the gather waves fetch the first mode of the first tile)
-    int stage = 0;
+    // Loop state kept incrementally (no divisions in the k-block loop: two waves of a SIMD run this program in
+    // lockstep, so whatever sits between two k-blocks' MFMAs idles the matrix pipe for both): (mode, kb) = k-block
+    // being multiplied, gpre = k-block whose fragments are fetched next (three ahead, wrapping into the next tile).
+    int stage = 0, mode = 0, kb = 0, gpre = 3 % nkb3;
+    const int tail_steps = (p.d - (nkb - 1) * KS) >> 2;     // MFMA steps of a mode's last k-block (1..4)
+    const float *arow = As + fr * lda + fq;
+    float an0[4], an1[4];                                   // A fragments of the NEXT k-block, read one k-block ahead
+    auto aload = [&](int st, int kblock) {
+      const float *ab = arow + (st & 1) * BM * lda + kblock * KS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        an0[i] = ab[4 * i];             // steps past the row width read the neighbouring row or the staging tile
+        an1[i] = ab[16 * lda + 4 * i];  // (inside the LDS block) and are not used
+      }
+    };
+    aload(0, 0);
     for (int it = 0; it < my_tiles; ++it) {
-      const int r0 = (int(blockIdx.x) + it * int(gridDim.x)) * BM;   // local row (node - node0) of the tile
-      if (it > 0 && !(p.ablate & 4)) {   // rows of the previous tile: staged during its last stage, visible since the barrier
-        const int pr0 = r0 - int(gridDim.x) * BM;
-        for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
-          const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-          if (pr0 + lrow < p.node1 - p.node0)
-            *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
-        }
-      }
-      f32x4 acc[2][NTW];
+      f32x4 acc[2][QF], acch = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < QF; ++t) acc[0][t] = acc[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-      // one k-block: MFMAs on fragment set `wc`, which is then refilled with the k-block three ahead
-#define MGCN_KBLOCK(wc, G)                                                                                   \
-      {                                                                                                      \
-        const int g_ = (G);                                                                                  \
-        const int mode_ = g_ / nkb, kb_ = g_ - mode_ * nkb;                                                  \
-        const float *abase_ = As + ((stage + mode_) & 1) * BM * lda + fr * lda + fq + kb_ * KS;              \
-        const int left_ = (p.d - kb_ * KS) >> 2;                                                             \
-        const int nsteps_ = (p.ablate & 2) ? 0 : (left_ < 4 ? left_ : 4);                                    \
-        float a0_[4], a1_[4];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-          a0_[i] = (i < nsteps_) ? abase_[4 * i] : 0.f;                                                      \
-          a1_[i] = (i < nsteps_) ? abase_[16 * lda + 4 * i] : 0.f;                                           \
-        }                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-          if (i < nsteps_) {                                                                                 \
-            _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                \
-              const float bv_ = i == 0 ? wc[t].x : i == 1 ? wc[t].y : i == 2 ? wc[t].z : wc[t].w;           \
-              if (t < nct) {                                                                                 \
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[i], bv_, acc[0][t], 0, 0, 0);           \
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[i], bv_, acc[1][t], 0, 0, 0);           \
-              }                                                                                              \
-            }                                                                                                \
-          }                                                                                                  \
-        }                                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < NTW; ++t) wc[t] = wload((g_ + 3) % nkb3, t);                   \
-        if (kb_ == nkb - 1) {                                                                                \
-          if (mode_ == 2 && !(p.ablate & 8)) epilogue_to_staging();                                          \
-          __syncthreads(); /* end of stage */                                                                \
-        }                                                                                                    \
-      }
-
-      auto epilogue_to_staging = [&]() {  // /3, bias, BN(eval), tanh; lane holds rows rt*16+fq*4+j, column (ct0+t)*16+fr
+      auto accumulators_to_staging = [&]() {  // lane holds rows rt*16 + fq*4 + j of column ct*16 + fr (raw sums)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const int col = (ct0 + t) * 16 + fr;
-          if (t >= nct || col >= p.o) continue;
-          const float cb = p.bias ? p.bias[col] : 0.f;
-          const float mean = p.bn_mean[col];
-          const float inv = 1.0f / sqrtf(p.bn_var[col] + p.bn_eps);
-          const float gam = p.bn_gamma[col], bet = p.bn_beta[col];
+        for (int t = 0; t < Q4; ++t) {
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v = acc[rt][t][j] / 3.0f;
-              if (p.bias) v = v + cb;
-              Os[(rt * 16 + fq * 4 + j) * LDO + col] = tanhf_((v - mean) * inv * gam + bet);
-            }
+            for (int j = 0; j < 4; ++j) Os[(rt * 16 + fq * 4 + j) * LDO + (ct0 + t) * 16 + fr] = acc[rt][t][j];
           }
+        }
+        if (has_half) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Os[((hrt ? 16 : 0) + fq * 4 + j) * LDO + hct * 16 + fr] = acch[j];
         }
       };
 
+#define MGCN_STEP(wc, i)                                                                                     \
+      _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                      \
+        const float bv_ = (i) == 0 ? wc[t].x : (i) == 1 ? wc[t].y : (i) == 2 ? wc[t].z : wc[t].w;           \
+        if (t < Q4) {                                                                                        \
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[i], bv_, acc[0][t], 0, 0, 0);                 \
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[i], bv_, acc[1][t], 0, 0, 0);                 \
+        } else if (has_half) {                                                                               \
+          acch = __builtin_amdgcn_mfma_f32_16x16x4f32(hrt ? a1_[i] : a0_[i], bv_, acch, 0, 0, 0);            \
+        }                                                                                                    \
+      }
+      // one k-block: MFMAs on fragment set `wc`, which is then refilled with the k-block three ahead
+#define MGCN_KBLOCK(wc)                                                                                      \
+      {                                                                                                      \
+        float a0_[4], a1_[4];                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { a0_[i] = an0[i]; a1_[i] = an1[i]; }                  \
+        const bool last_ = kb == nkb - 1;                                                                    \
+        const int nsteps_ = (p.ablate & 2) ? 0 : (last_ ? tail_steps : 4);                                   \
+        if (!last_) aload(stage + mode, kb + 1);                                                             \
+        if (nsteps_ > 0) { MGCN_STEP(wc, 0) }                                                                \
+        if (nsteps_ > 1) { MGCN_STEP(wc, 1) }                                                                \
+        if (nsteps_ > 2) { MGCN_STEP(wc, 2) }                                                                \
+        if (nsteps_ > 3) { MGCN_STEP(wc, 3) }                                                                \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) wc[t] = wload(gpre, t);                              \
+        gpre = gpre + 1 == nkb3 ? 0 : gpre + 1;                                                              \
+        if (last_) {                                                                                         \
+          if (mode == 2) accumulators_to_staging();                                                          \
+          __syncthreads(); /* end of stage: the next mode's tile is complete */                              \
+          kb = 0;                                                                                            \
+          mode = mode == 2 ? 0 : mode + 1;                                                                   \
+          if (mode == 0) stage += 3;                                                                         \
+          aload(stage + mode, 0);                                                                            \
+        } else {                                                                                             \
+          ++kb;                                                                                              \
+        }                                                                                                    \
+      }
+
       for (int g0 = 0; g0 < nkb3; g0 += 3) {   // nkb3 is a multiple of 3: fragment sets rotate w0 -> w1 -> w2
-        MGCN_KBLOCK(w0, g0)
-        MGCN_KBLOCK(w1, g0 + 1)
-        MGCN_KBLOCK(w2, g0 + 2)
+        MGCN_KBLOCK(w0)
+        MGCN_KBLOCK(w1)
+        MGCN_KBLOCK(w2)
       }
 #undef MGCN_KBLOCK
-      stage += 3;
-    }
-    if (!(p.ablate & 4)) {                     // rows of the last tile
-      const int pr0 = (int(blockIdx.x) + (my_tiles - 1) * int(gridDim.x)) * BM;
-      for (int s4 = tid; s4 < BM * c4n; s4 += 256) {
-        const int lrow = s4 / c4n, lc = (s4 - lrow * c4n) * 4;
-        if (pr0 + lrow < p.node1 - p.node0)
-          *reinterpret_cast<float4 *>(p.out + int64_t(pr0 + lrow) * p.ldo + lc) = *reinterpret_cast<const float4 *>(Os + lrow * LDO + lc);
-      }
+#undef MGCN_STEP
     }
   }
 }
