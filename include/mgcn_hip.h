@@ -75,7 +75,8 @@ const char *mgcn_last_error(void);
  *                                walk the destination runs / hub chunks of the other half through this map;
  *   typeptr_host [num_rel_rows+1] int32, typeslots_host [2E] int32
  *                                all slots (ascending) grouped by relation-table row.
- * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows).
+ * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows-1): the last row of the
+ * relation table is the self-loop row (model.py:86), which only the self-loop pass reads.
  */
 int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_rel_rows,
                         const int64_t *edge_index_host, const int64_t *edge_type_host,
@@ -155,8 +156,8 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * the same block without ever reaching HBM. Arguments as in (2) and (4), except that the weights are passed in MFMA
  * fragment order: wp_dev = mgcn_pack_weights() of the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes
  * bytes, 16-byte aligned; re-pack whenever a weight changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all
- * operands are 16-byte aligned, dim_in % 4 == 0, dim_in <= 256, dim_out % 4 == 0 and dim_out <= 208 — callers then
- * use (2) followed by (4).
+ * operands are 16-byte aligned, ee_dev is given in slot order, dim_in % 4 == 0, dim_in <= 256, dim_out % 4 == 0 and
+ * dim_out <= 208 — callers then use (2) followed by (4).
  * Destination partition: only destinations [node_begin, node_end) are computed; out_dev holds THOSE rows
  * (row 0 = node_begin). A rank may hold only its shard of the slot-ordered per-edge table — the rows of the in-half
  * slots [rowptr_in[node_begin], rowptr_in[node_end]) followed by those of the out-half slots of the same nodes — and

@@ -42,9 +42,10 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
     MGCN_REQUIRE(src[e] >= 0 && src[e] < N && dst[e] >= 0 && dst[e] < N,
                  "csr_build: edge %lld endpoint (%lld -> %lld) outside [0, %lld)", (long long)e,
                  (long long)src[e], (long long)dst[e], (long long)N);
-    MGCN_REQUIRE(edge_type_host[e] >= 0 && edge_type_host[e] < num_rel_rows,
-                 "csr_build: edge %lld type %lld outside [0, %lld)", (long long)e,
-                 (long long)edge_type_host[e], (long long)num_rel_rows);
+    // the LAST row of the relation table is the self-loop row (model.py:86,91): only the self-loop pass uses it
+    MGCN_REQUIRE(edge_type_host[e] >= 0 && edge_type_host[e] < num_rel_rows - 1,
+                 "csr_build: edge %lld type %lld outside [0, %lld) (row %lld is the self-loop row)", (long long)e,
+                 (long long)edge_type_host[e], (long long)(num_rel_rows - 1), (long long)(num_rel_rows - 1));
   }
   // ---- pass 1: destination counts per half; a destination with more than hub_threshold slots in a half is a hub
   std::vector<int32_t> cnt(2 * N, 0);

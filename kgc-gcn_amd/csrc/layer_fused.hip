@@ -135,6 +135,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     const int g_lo = grp * rpg, g_hi = g_lo + rpg;
     const bool col_ok = lig * 4 < p.d;
     const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
+    const float *xb = p.x + coff, *relb = p.rel + coff, *eeb = p.ee + coff;
+    const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
     auto finalize = [&](int tile_it) {
       if (!(p.ablate & 4)) finalize_tile(p, Os, LDO, (int(blockIdx.x) + tile_it * int(gridDim.x)) * BM, gtid);
     };
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
         } else if (mode < 2) {
           const int myrp = currp;
           int4 myrec = currec;
+          const int ee_sub_mode = int(p.ee_sub[mode]);   // (a kernel argument indexed by the loop variable: read it once)
           const bool has_next = mode == 0 || it + 1 < my_tiles;   // next stage with records: (it, 1) or (it + 1, 0)
           int nrp = 0;
           if (has_next) nrp = rp_of(mode == 0 ? it : it + 1, mode == 0 ? 1 : 0);
@@ -190,25 +193,21 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
               cbase += gs;
               myrec = rec_chunk(cbase, end);
             }
-            int rsrc[U], rtyp[U], rnrm[U], reid[U];
+            int rsrc[U], rtyp[U], rnrm[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
               const int from = glane0 + (((s + u < end) ? s + u : end - 1) - cbase);
               rsrc[u] = __shfl(myrec.x, from);
               rtyp[u] = __shfl(myrec.y, from);
               rnrm[u] = __shfl(myrec.z, from);
-              if (p.ee && !p.ee_slot_order) reid[u] = __shfl(myrec.w, from);
             }
-            float4 xv[U], rv[U], ev[U];
+            float4 xv[U], rv[U], ev[U];   // row addresses: one unsigned 32 x 32 -> 64 multiply-add each
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              xv[u] = *reinterpret_cast<const float4 *>(p.x + int64_t(rsrc[u]) * p.ldx + coff);
-              const float *rr = (rtyp[u] < p.rel_rows - 1) ? p.rel + int64_t(rtyp[u]) * p.d : p.loop_rel;
-              rv[u] = *reinterpret_cast<const float4 *>(rr + coff);
-              if (p.ee) {
-                const int64_t slot = (s + u < end) ? s + u : end - 1;
-                ev[u] = *reinterpret_cast<const float4 *>(p.ee + (p.ee_slot_order ? slot - p.ee_sub[mode] : int64_t(reid[u])) * p.d + coff);
-              }
+              xv[u] = *reinterpret_cast<const float4 *>(xb + uint64_t(uint32_t(rsrc[u])) * ldx32);
+              rv[u] = *reinterpret_cast<const float4 *>(relb + uint64_t(uint32_t(rtyp[u])) * d32);   // graph edges never use the self-loop row
+              const uint32_t erow = uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
+              ev[u] = *reinterpret_cast<const float4 *>(eeb + uint64_t(erow) * d32);
             }
             if (!next_recs_issued) {   // behind this batch's row loads: the next stage's records (its row pointers are back)
               next_recs_issued = true;
@@ -228,8 +227,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
                   ++row;
                   nb = __shfl(myrp, glane0 + (row - g_lo) + 1);
                 }
-                float4 m = f4mul(xv[u], rv[u]);
-                if (p.ee) m = f4mul(m, ev[u]);
+                const float4 m = f4mul(f4mul(xv[u], rv[u]), ev[u]);
                 const float wgt = __int_as_float(rnrm[u]);
                 sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
               }
@@ -420,9 +418,10 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
                        mgcn::aligned16(loop_edge_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
                        mgcn::aligned16(out_dev) && mgcn::aligned16(wp_dev) && ldx % 4 == 0 && ldo % 4 == 0;
-  if (!aligned || dim_in % 4 != 0 || dim_in > 256 || dim_out % 4 != 0 || dim_out > 208)
-    return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, D %% 4 == 0, D <= 256, "
-                      "O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
+  if (!aligned || dim_in % 4 != 0 || dim_in > 256 || dim_out % 4 != 0 || dim_out > 208 || !ee_dev || !ee_in_slot_order ||
+      ldx >= (int64_t(1) << 31))
+    return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, a per-edge table in slot order, "
+                      "D %% 4 == 0, D <= 256, O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
   const int64_t num_chunks = chunk_end - chunk_begin;
   MGCN_REQUIRE(chunk_begin >= 0 && num_chunks >= 0 && chunk_end < (int64_t(1) << 31) &&
                    (num_chunks == 0 || (hubinfo_dev && chunks_dev && partial_dev && mgcn::aligned16(partial_dev))),

@@ -161,7 +161,7 @@ class MGCNConv(nn.Module):
             all_ent = torch.empty((num_ent, self.out_channels), dtype=torch.float32, device=x.device)
             bn = self.ent_bn
             wcat, wpack = (self._wcat, self._wpack) if _capturing(x) else self.derived_weights()
-            if wpack is not None:
+            if wpack is not None and ee_in_slot_order:   # (a table in edge-id order takes the two-launch path)
                 _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
                                         ee_in_slot_order, self.loop_edge.reshape(-1), wpack, self.out_channels, self.bias,
                                         bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)

@@ -129,6 +129,8 @@ def test_feeder_rejects_bad_input(pkg):
         pkg._native.csr_build_host(3, 3, ei, torch.tensor([0, 1]))
     with pytest.raises(pkg._native.NativeError, match='type'):
         pkg._native.csr_build_host(6, 1, ei, torch.tensor([0, 1]))
+    with pytest.raises(pkg._native.NativeError, match='self-loop row'):    # the last relation row belongs to the self-loop pass
+        pkg._native.csr_build_host(6, 3, ei, torch.tensor([0, 2]))
     h = pkg._native.csr_build_host(4, 3, torch.empty((2, 0), dtype=torch.int64), torch.empty(0, dtype=torch.int64))
     assert h['rowptr'].abs().sum() == 0                                    # empty graph
 
