@@ -86,8 +86,8 @@ __device__ __forceinline__ void finalize_tile(const FusedArgs &p, const float *O
   const float4 gam = *reinterpret_cast<const float4 *>(p.bn_gamma + fcol);
   const float4 bet = *reinterpret_cast<const float4 *>(p.bn_beta + fcol);
   const float4 cb = p.bias ? *reinterpret_cast<const float4 *>(p.bias + fcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 inv = make_float4(1.0f / sqrtf(var.x + p.bn_eps), 1.0f / sqrtf(var.y + p.bn_eps),
-                                 1.0f / sqrtf(var.z + p.bn_eps), 1.0f / sqrtf(var.w + p.bn_eps));
+  const float4 inv = make_float4(__builtin_amdgcn_rsqf(var.x + p.bn_eps), __builtin_amdgcn_rsqf(var.y + p.bn_eps),
+                                 __builtin_amdgcn_rsqf(var.z + p.bn_eps), __builtin_amdgcn_rsqf(var.w + p.bn_eps));
   for (int lrow = frow0; lrow < BM; lrow += rstep) {
     if (pr0 + lrow >= p.node1 - p.node0) break;
     float4 v = *reinterpret_cast<const float4 *>(Os + lrow * ldo_s + fcol);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     const int rpg = (BM * gs) / 256;                 // destinations per group (>= 1, < gs)
     const int g_lo = grp * rpg, g_hi = g_lo + rpg;
     const bool col_ok = lig * 4 < p.d;
-    const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width read column 0 and never write
+    const int coff = col_ok ? lig * 4 : 0;           // lanes past the row width duplicate lane 0 (columns 0-3)
     const float *xb = p.x + coff, *relb = p.rel + coff, *eeb = p.ee + coff;
     const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
     auto finalize = [&](int tile_it) {
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
               if (s + u < end) {
                 while (s + u >= nb) {  // group-uniform: the run of destination `row` is complete
                   add_hub(row);
-                  if (col_ok) {
-                    float *dst = at + row * lda + lig * 4;
+                  {   // (lanes past the row width carry lane 0's columns: same address, same value, no branch)
+                    float *dst = at + row * lda + coff;
                     *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
                     *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
                   }
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
           currec = nrec;
           for (; row < g_hi; ++row) {  // last run, then zero rows for destinations without slots
             add_hub(row);
-            if (col_ok) {
-              float *dst = at + row * lda + lig * 4;
+            {
+              float *dst = at + row * lda + coff;
               *reinterpret_cast<float2 *>(dst) = make_float2(sum.x, sum.y);
               *reinterpret_cast<float2 *>(dst + 2) = make_float2(sum.z, sum.w);
             }
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
           for (int row = g_lo; row < g_hi; ++row) {
             const int node = (r0 + row < p.node1) ? r0 + row : p.node1 - 1;  // rows past the range are computed, never stored
             const float4 v = f4mul(f4mul(*reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff), lr), le);
-            if (col_ok) {
-              float *dst = at + row * lda + lig * 4;
+            {
+              float *dst = at + row * lda + coff;
               *reinterpret_cast<float2 *>(dst) = make_float2(v.x, v.y);
               *reinterpret_cast<float2 *>(dst + 2) = make_float2(v.z, v.w);
             }
@@ -299,16 +299,19 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     int stage = 0, mode = 0, kb = 0, gpre = 3 % nkb3;
     const int tail_steps = (p.d - (nkb - 1) * KS) >> 2;     // MFMA steps of a mode's last k-block (1..4)
     const float *arow = As + fr * lda + fq;
-    float an0[4], an1[4];                                   // A fragments of the NEXT k-block, read one k-block ahead
-    auto aload = [&](int st, int kblock) {
-      const float *ab = arow + (st & 1) * BM * lda + kblock * KS;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        an0[i] = ab[4 * i];             // steps past the row width read the neighbouring row or the staging tile
-        an1[i] = ab[16 * lda + 4 * i];  // (inside the LDS block) and are not used
-      }
-    };
-    aload(0, 0);
+    // A fragments are read ONE k-block ahead into the register set of the next k-block (three sets rotating with
+    // the weight sets, so no copies): steps past the row width read the neighbouring row or the staging tile
+    // (inside the LDS block) and are not used.
+    float aA[2][4], aB[2][4], aC[2][4];
+#define MGCN_ALOAD(dst, st, kblock)                                                                          \
+    {                                                                                                        \
+      const float *ab_ = arow + ((st) & 1) * BM * lda + (kblock) * KS;                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+        dst[0][i] = ab_[4 * i];                                                                              \
+        dst[1][i] = ab_[16 * lda + 4 * i];                                                                   \
+      }                                                                                                      \
+    }
+    MGCN_ALOAD(aA, 0, 0)
     for (int it = 0; it < my_tiles; ++it) {
       f32x4 acc[2][QF], acch = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -329,28 +332,27 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
         }
       };
 
-#define MGCN_STEP(wc, i)                                                                                     \
+#define MGCN_STEP(wc, ac, i)                                                                                 \
       _Pragma("unroll") for (int t = 0; t < NTW; ++t) {                                                      \
         const float bv_ = (i) == 0 ? wc[t].x : (i) == 1 ? wc[t].y : (i) == 2 ? wc[t].z : wc[t].w;           \
         if (t < Q4) {                                                                                        \
-          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[i], bv_, acc[0][t], 0, 0, 0);                 \
-          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[i], bv_, acc[1][t], 0, 0, 0);                 \
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][i], bv_, acc[0][t], 0, 0, 0);               \
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][i], bv_, acc[1][t], 0, 0, 0);               \
         } else if (has_half) {                                                                               \
-          acch = __builtin_amdgcn_mfma_f32_16x16x4f32(hrt ? a1_[i] : a0_[i], bv_, acch, 0, 0, 0);            \
+          if (hrt) acch = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][i], bv_, acch, 0, 0, 0);                \
+          else acch = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][i], bv_, acch, 0, 0, 0);                    \
         }                                                                                                    \
       }
       // one k-block: MFMAs on fragment set `wc`, which is then refilled with the k-block three ahead
-#define MGCN_KBLOCK(wc)                                                                                      \
+#define MGCN_KBLOCK(wc, ac, an)                                                                              \
       {                                                                                                      \
-        float a0_[4], a1_[4];                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) { a0_[i] = an0[i]; a1_[i] = an1[i]; }                  \
         const bool last_ = kb == nkb - 1;                                                                    \
         const int nsteps_ = (p.ablate & 2) ? 0 : (last_ ? tail_steps : 4);                                   \
-        if (!last_) aload(stage + mode, kb + 1);                                                             \
-        if (nsteps_ > 0) { MGCN_STEP(wc, 0) }                                                                \
-        if (nsteps_ > 1) { MGCN_STEP(wc, 1) }                                                                \
-        if (nsteps_ > 2) { MGCN_STEP(wc, 2) }                                                                \
-        if (nsteps_ > 3) { MGCN_STEP(wc, 3) }                                                                \
+        if (!last_) MGCN_ALOAD(an, stage + mode, kb + 1)                                                     \
+        if (nsteps_ > 0) { MGCN_STEP(wc, ac, 0) }                                                            \
+        if (nsteps_ > 1) { MGCN_STEP(wc, ac, 1) }                                                            \
+        if (nsteps_ > 2) { MGCN_STEP(wc, ac, 2) }                                                            \
+        if (nsteps_ > 3) { MGCN_STEP(wc, ac, 3) }                                                            \
         _Pragma("unroll") for (int t = 0; t < NTW; ++t) wc[t] = wload(gpre, t);                              \
         gpre = gpre + 1 == nkb3 ? 0 : gpre + 1;                                                              \
         if (last_) {                                                                                         \
@@ -359,19 +361,20 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
           kb = 0;                                                                                            \
           mode = mode == 2 ? 0 : mode + 1;                                                                   \
           if (mode == 0) stage += 3;                                                                         \
-          aload(stage + mode, 0);                                                                            \
+          MGCN_ALOAD(an, stage + mode, 0)                                                                    \
         } else {                                                                                             \
           ++kb;                                                                                              \
         }                                                                                                    \
       }
 
       for (int g0 = 0; g0 < nkb3; g0 += 3) {   // nkb3 is a multiple of 3: fragment sets rotate w0 -> w1 -> w2
-        MGCN_KBLOCK(w0)
-        MGCN_KBLOCK(w1)
-        MGCN_KBLOCK(w2)
+        MGCN_KBLOCK(w0, aA, aB)
+        MGCN_KBLOCK(w1, aB, aC)
+        MGCN_KBLOCK(w2, aC, aA)
       }
 #undef MGCN_KBLOCK
 #undef MGCN_STEP
+#undef MGCN_ALOAD
     }
   }
 }
