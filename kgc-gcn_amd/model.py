@@ -244,6 +244,7 @@ class MGCN(nn.Module):
         self._slot_csr = None      # per-edge tables are stored in this CSR's slot order (None = reference order)
         self._enc_cache = None
         self._hip_graph = None
+        self._hip_graph_disabled = False
         self._register_state_dict_hook(MGCN._to_reference_order)
         self.register_load_state_dict_post_hook(MGCN._loaded_reference_order)
 
@@ -315,7 +316,7 @@ class MGCN(nn.Module):
         stamp = (id(csr),) + tuple(t._version for t in tensors) + tuple(t.data_ptr() for t in tensors)
         if use_cache and self._enc_cache is not None and self._enc_cache[0] == stamp:
             return self._enc_cache[1], self._enc_cache[2]
-        if getattr(self.params, 'use_hip_graph', True) and self.entity_embedding.is_cuda:
+        if getattr(self.params, 'use_hip_graph', True) and self.entity_embedding.is_cuda and not self._hip_graph_disabled:
             out = self._encode_replay(data, csr, ent_identity, edge_identity, tensors)
         else:
             out = self._encode_layers(data, csr, ent_identity, edge_identity)
@@ -352,8 +353,17 @@ class MGCN(nn.Module):
                 self._encode_layers(data, csr, ent_identity, edge_identity)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._encode_layers(data, csr, ent_identity, edge_identity)
+            try:
+                # thread_local: other threads of the process (the RCCL watchdog of a live process group queries
+                # events) must not invalidate this thread's capture
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    out = self._encode_layers(data, csr, ent_identity, edge_identity)
+            except RuntimeError as err:                         # capture refused: the same launches, without a graph
+                import logging
+                logging.warning('hipGraph capture of the encoder failed (%s): launching the layers directly', err)
+                torch.cuda.synchronize()
+                self._hip_graph_disabled = True
+                return self._encode_layers(data, csr, ent_identity, edge_identity)
             hit = (key, graph, out)
             self._hip_graph = hit
         hit[1].replay()
