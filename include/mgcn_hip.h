@@ -49,6 +49,34 @@ int mgcn_abi_version(void);
 const char *mgcn_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * (0) Graph ingest on the host (replaces the two Python passes of data_loader.py:61-96 for triple
+ * files of 10^7-10^8 lines). mgcn_ingest_open reads the three split files (one `subject relation object` triple per
+ * line, any ASCII whitespace between tokens, universal newlines) and assigns entity / relation ids in first-seen
+ * order over train, valid, test — per line subject, relation, object — with names lower-cased on insertion
+ * (data_loader.py:64-70). Error behaviour follows the reference: a line without exactly three tokens is an error
+ * (its tuple unpacking raises ValueError); a token that lower-casing changes is an error naming the token (its raw
+ * lookup, data_loader.py:84-86, raises KeyError). A token with a byte >= 0x80 returns MGCN_EUNSUPPORTED (Python's
+ * str.lower() is Unicode-aware): use the Python reader for such files.
+ * mgcn_ingest_count: what = 0 entities, 1 relations (forward only; reverse relation r + R is implicit), 2 / 3 / 4 =
+ * triples of train / valid / test. mgcn_ingest_triples: [n, 3] int64 (s, r, o) ids of a split (0 / 1 / 2).
+ * mgcn_ingest_names: the names in id order as one byte string + [n+1] offsets (kind 0 entities, 1 relations).
+ */
+typedef struct mgcn_ingest mgcn_ingest;
+int mgcn_ingest_open(const char *train_path, const char *valid_path, const char *test_path, mgcn_ingest **out);
+void mgcn_ingest_close(mgcn_ingest *h);
+int64_t mgcn_ingest_count(const mgcn_ingest *h, int32_t what);
+int mgcn_ingest_triples(const mgcn_ingest *h, int32_t split, int64_t *triples_host);
+int64_t mgcn_ingest_names_bytes(const mgcn_ingest *h, int32_t kind);
+int mgcn_ingest_names(const mgcn_ingest *h, int32_t kind, char *bytes_host, int64_t *offsets_host);
+
+/* The loader's known-answer index (data_loader.py:80-96: sr2o over the given triples, both directions — the reverse
+ * query of (s, r, o) is (o, r + R, s)) in the form mgcn_filter_mask reads: sorted keys s * 2R + r, CSR pointers,
+ * sorted distinct tails. Call with keys_host == NULL to obtain *num_keys / *num_tails, then with buffers of those sizes
+ * (keys [num_keys], ptr [num_keys + 1], tails [num_tails]). */
+int mgcn_filter_index_build(int64_t num_triples, const int64_t *triples_host, int64_t num_relations, int64_t *keys_host,
+                            int64_t *ptr_host, int32_t *tails_host, int64_t *num_keys, int64_t *num_tails);
+
+/* ---------------------------------------------------------------------------------------------
  * (1) Feeder — host side. Replaces data_loader.py:132-157 (`_build_graph`: the bi-directional edge
  * list) as consumed by model.py:88-97 (split into the in-half [0,E) and out-half [E,2E), degree
  * norms per half, `compute_norm` model.py:72-80, hoisted out of the step because the graph is

@@ -39,6 +39,13 @@ _SIGNATURES = {
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
                                        _ptr, _i64, _ptr, _ptr]),
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
+    'mgcn_ingest_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_ptr)]),
+    'mgcn_ingest_close': (None, [_ptr]),
+    'mgcn_ingest_count': (_i64, [_ptr, _i32]),
+    'mgcn_ingest_triples': (ctypes.c_int, [_ptr, _i32, _ptr]),
+    'mgcn_ingest_names_bytes': (_i64, [_ptr, _i32]),
+    'mgcn_ingest_names': (ctypes.c_int, [_ptr, _i32, _ptr, _ptr]),
+    'mgcn_filter_index_build': (ctypes.c_int, [_i64, _ptr, _i64, _ptr, _ptr, _ptr, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))
@@ -379,3 +386,61 @@ def filter_mask(qkey, keys, ptr, tails, n_local, ent_row0=0, out=None):
                                   int(n_local), _dev(out, torch.int32, 'mask'), out.size(1), _stream(qkey)),
            'mgcn_filter_mask')
     return out
+
+
+class IngestUnsupported(NativeError):
+    """The native reader declined the files (non-ASCII names): use the Python reader."""
+
+
+def ingest(train_path, valid_path, test_path):
+    """(0) Native reader of the three split files. Returns (entity_names, relation_names, {split: [n, 3] int64 ids}):
+    names in id order (first-seen over train, valid, test; lower-cased), ids as data_loader.py:84-86 assigns them.
+    Raises ValueError / KeyError where the reference's reader does, IngestUnsupported for non-ASCII names."""
+    handle = _ptr()
+    rc = lib().mgcn_ingest_open(os.fsencode(train_path), os.fsencode(valid_path), os.fsencode(test_path),
+                                ctypes.byref(handle))
+    if rc != 0:
+        msg = (lib().mgcn_last_error() or b'').decode('utf-8', 'replace')
+        if rc == 3:
+            raise IngestUnsupported(msg)
+        if 'KeyError' in msg:
+            raise KeyError(msg.split("'")[1] if "'" in msg else msg)
+        if 'ValueError' in msg:
+            raise ValueError(msg)
+        if 'cannot open' in msg:
+            raise FileNotFoundError(msg)
+        raise NativeError('mgcn_ingest_open failed (%d): %s' % (rc, msg))
+    try:
+        names = []
+        for kind in (0, 1):
+            n, nbytes = lib().mgcn_ingest_count(handle, kind), lib().mgcn_ingest_names_bytes(handle, kind)
+            buf = ctypes.create_string_buffer(max(int(nbytes), 1))
+            offs = torch.empty(n + 1, dtype=torch.int64)
+            _check(lib().mgcn_ingest_names(handle, kind, ctypes.cast(buf, _ptr), offs.data_ptr()), 'mgcn_ingest_names')
+            raw, o = buf.raw, offs.tolist()
+            names.append([raw[o[i]:o[i + 1]].decode('ascii') for i in range(n)])
+        ids = {}
+        for k, split in enumerate(('train', 'valid', 'test')):
+            t = torch.empty((int(lib().mgcn_ingest_count(handle, 2 + k)), 3), dtype=torch.int64)
+            _check(lib().mgcn_ingest_triples(handle, k, t.data_ptr() if t.numel() else None), 'mgcn_ingest_triples')
+            ids[split] = t
+        return names[0], names[1], ids
+    finally:
+        lib().mgcn_ingest_close(handle)
+
+
+def filter_index_build(triples, num_relations):
+    """Known-answer index of [n, 3] int64 id triples, both directions: (keys [K] int64, ptr [K+1] int64, tails int32),
+    all host tensors (see mgcn_filter_index_build)."""
+    t = triples.detach().to('cpu', torch.int64).contiguous().reshape(-1, 3)
+    nk, nt = _i64(0), _i64(0)
+    tp = t.data_ptr() if t.numel() else None
+    _check(lib().mgcn_filter_index_build(t.size(0), tp, int(num_relations), None, None, None, ctypes.byref(nk),
+                                         ctypes.byref(nt)), 'mgcn_filter_index_build')
+    keys = torch.empty(nk.value, dtype=torch.int64)
+    ptr = torch.empty(nk.value + 1, dtype=torch.int64)
+    tails = torch.empty(nt.value, dtype=torch.int32)
+    _check(lib().mgcn_filter_index_build(t.size(0), tp, int(num_relations), keys.data_ptr(), ptr.data_ptr(),
+                                         tails.data_ptr() if nt.value else None, ctypes.byref(nk), ctypes.byref(nt)),
+           'mgcn_filter_index_build')
+    return keys, ptr, tails

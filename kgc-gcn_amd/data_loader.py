@@ -49,6 +49,10 @@ class KBDataset(data.Dataset):
 class DataLoader(object):
     def __init__(self, dataset, params):
         self.data_dir = os.path.join('data', dataset)
+        # params.ingest_only (extension, default False): keep only what scales to 10^8 triples — ids, the graph, the
+        # device filter index and the evaluation query tensor, all from the native reader; no per-query dict lists
+        # (`triplets`, get_data_loaders), which are what main.py's loaders need and what costs the Python time.
+        self._ingest_only = bool(getattr(params, 'ingest_only', False))
         self.graph = self._load_data()
 
     # -- reading ---------------------------------------------------------------------------------
@@ -56,7 +60,8 @@ class DataLoader(object):
         with open(os.path.join(self.data_dir, split + '.txt'), 'r') as f:
             return [line.strip().split() for line in f]
 
-    def _load_data(self):
+    def _read_ids_python(self):
+        """data_loader.py:61-86 literally: two passes with dict lookups (ids built lower-cased, looked up raw)."""
         raw = {split: self._read(split) for split in ('train', 'valid', 'test')}
         self.entity2id, self.relation2id = {}, {}
         for split in ('train', 'valid', 'test'):
@@ -64,13 +69,45 @@ class DataLoader(object):
                 self.entity2id.setdefault(h.lower(), len(self.entity2id))
                 self.relation2id.setdefault(r.lower(), len(self.relation2id))
                 self.entity2id.setdefault(t.lower(), len(self.entity2id))
+        return {split: [(self.entity2id[h], self.relation2id[r], self.entity2id[t]) for h, r, t in raw[split]]
+                for split in ('train', 'valid', 'test')}
+
+    def _read_ids_native(self, as_lists=True):
+        """The same ids from the native reader (mgcn_ingest_*): one pass in C++, same insertion order,
+        same errors. Returns None for files it declines (non-ASCII names)."""
+        from . import _native
+        paths = [os.path.join(self.data_dir, split + '.txt') for split in ('train', 'valid', 'test')]
+        try:
+            ent, rel, ids = _native.ingest(*paths)
+        except _native.IngestUnsupported:
+            return None
+        self.entity2id = {name: i for i, name in enumerate(ent)}
+        self.relation2id = {name: i for i, name in enumerate(rel)}
+        self._id_triples = ids                                   # [n, 3] int64 per split, for filter_index()
+        if not as_lists:
+            return ids
+        return {split: [tuple(row) for row in t.tolist()] for split, t in ids.items()}
+
+    def _load_data(self):
+        self._id_triples = None
+        ids = None
+        if os.environ.get('MGCN_NATIVE_INGEST', '1') != '0':
+            ids = self._read_ids_native(as_lists=not self._ingest_only)
+        if ids is None:
+            ids = self._read_ids_python()
         nrel = len(self.relation2id)
         self.relation2id.update({name + '_reverse': idx + nrel for name, idx in list(self.relation2id.items())})
         self.num_entity, self.num_relation = len(self.entity2id), nrel
+        if self._ingest_only:
+            if self._id_triples is None:
+                self._id_triples = {k: torch.tensor(v, dtype=torch.int64).reshape(-1, 3) for k, v in ids.items()}
+            self.triplets, self._known_all = None, None
+            self.num_edge = int(self._id_triples['train'].size(0))
+            return self._build_graph(np.arange(self.num_entity, dtype=np.int64), self._id_triples['train'].numpy(),
+                                     bi_direction=True)
 
-        ids, known, known_train = {}, {}, None
+        known, known_train = {}, None
         for split in ('train', 'valid', 'test'):
-            ids[split] = [(self.entity2id[h], self.relation2id[r], self.entity2id[t]) for h, r, t in raw[split]]
             for s, p, o in ids[split]:
                 known.setdefault((s, p), set()).add(o)
                 known.setdefault((o, p + nrel), set()).add(s)
@@ -121,15 +158,26 @@ class DataLoader(object):
         """Device-side form of the evaluation filter (every known tail of every (subject, relation), i.e. what the
         dense label rows of the *_head / *_tail datasets mark): see dist.FilterIndex."""
         from .dist import FilterIndex
+        if self._id_triples is not None:                         # sort-based build in C++ (mgcn_filter_index_build)
+            from . import _native
+            triples = torch.cat([self._id_triples[s] for s in ('train', 'valid', 'test')], dim=0)
+            keys, ptr, tails = _native.filter_index_build(triples, self.num_relation)
+            return FilterIndex(keys, ptr, tails, 2 * self.num_relation)
         return FilterIndex.from_known(self._known_all, 2 * self.num_relation)
 
     def eval_queries(self, split):
         """[Q, 3] int64 (subject, relation id, object): the split's tail queries followed by its head queries."""
+        if self._id_triples is not None:
+            t = self._id_triples[split]
+            heads = torch.stack([t[:, 2], t[:, 1] + self.num_relation, t[:, 0]], dim=1)
+            return torch.cat([t, heads], dim=0).contiguous()
         rows = [q['triple'] for q in self.triplets[split + '_tail']] + [q['triple'] for q in self.triplets[split + '_head']]
         return torch.tensor(rows, dtype=torch.int64).reshape(-1, 3)
 
     # -- query loaders ---------------------------------------------------------------------------
     def _get_dataset(self, data_type, params):
+        if self.triplets is None:
+            raise ValueError('this DataLoader was built with ingest_only: no per-query lists (use eval_queries / filter_index)')
         if data_type == 'train':
             return KBDataset(self.triplets['train'], self.num_entity, params, training=True)
         if data_type in ('valid_head', 'valid_tail', 'test_head', 'test_tail'):

@@ -184,6 +184,133 @@ def test_label_rows_and_smoothing(pkg, case):
     assert set(row.unique().tolist()) <= {0.0, 1.0}
 
 
+def _write_splits(root, name, texts):
+    d = root / 'data' / name
+    d.mkdir(parents=True)
+    for split, text in zip(('train', 'valid', 'test'), texts):
+        (d / (split + '.txt')).write_bytes(text.encode('utf-8') if isinstance(text, str) else text)
+    return d
+
+
+def _load_in(pkg, root, name, native):
+    cwd = os.getcwd()
+    os.chdir(root)
+    old = os.environ.get('MGCN_NATIVE_INGEST')
+    os.environ['MGCN_NATIVE_INGEST'] = '1' if native else '0'
+    try:
+        return pkg.DataLoader(name, types.SimpleNamespace(lbl_smooth=0.0))
+    finally:
+        os.chdir(cwd)
+        if old is None:
+            os.environ.pop('MGCN_NATIVE_INGEST', None)
+        else:
+            os.environ['MGCN_NATIVE_INGEST'] = old
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+def test_native_ingest_equals_python_reader(pkg, case):
+    """the C++ reader assigns the ids the two Python passes assign (goldens = the reference's own), and the
+    sort-based known-answer index equals the dict-of-sets one."""
+    g = golden(case)
+    root, name = os.path.dirname(os.path.dirname(g.data_dir)), os.path.basename(g.data_dir)
+    nat, py = _load_in(pkg, root, name, True), _load_in(pkg, root, name, False)
+    assert nat._id_triples is not None and py._id_triples is None
+    assert list(nat.entity2id.items()) == list(py.entity2id.items())        # same names, same ids, same insertion order
+    assert list(nat.relation2id.items()) == list(py.relation2id.items())
+    assert nat.triplets == py.triplets
+    assert np.array_equal(nat.graph.edge_index.numpy(), py.graph.edge_index.numpy())
+    a, b = nat.filter_index(), py.filter_index()
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.ptr, b.ptr) and torch.equal(a.tails, b.tails)
+    assert a.num_rel_ids == b.num_rel_ids
+
+
+def test_ingest_only_loader(pkg):
+    """The scalable subset (ids, graph, filter index, evaluation queries) without the per-query dict lists: identical
+    tensors to the full loader's."""
+    g = golden('syn_b')
+    root, name = os.path.dirname(os.path.dirname(g.data_dir)), os.path.basename(g.data_dir)
+    full = _load_in(pkg, root, name, True)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        lean = pkg.DataLoader(name, types.SimpleNamespace(lbl_smooth=0.0, ingest_only=True))
+    finally:
+        os.chdir(cwd)
+    assert lean.triplets is None and (lean.num_entity, lean.num_relation, lean.num_edge) == (full.num_entity, full.num_relation, full.num_edge)
+    assert np.array_equal(lean.graph.edge_index.numpy(), full.graph.edge_index.numpy())
+    assert np.array_equal(lean.graph.edge_attr.numpy(), full.graph.edge_attr.numpy())
+    for split in ('valid', 'test'):
+        rows = [q['triple'] for q in full.triplets[split + '_tail']] + [q['triple'] for q in full.triplets[split + '_head']]
+        assert torch.equal(lean.eval_queries(split), torch.tensor(rows, dtype=torch.int64).reshape(-1, 3))
+        assert torch.equal(full.eval_queries(split), lean.eval_queries(split))
+    a, b = lean.filter_index(), pkg.dist.FilterIndex.from_known(full._known_all, 2 * full.num_relation)
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.ptr, b.ptr) and torch.equal(a.tails, b.tails)
+    with pytest.raises(ValueError):
+        lean.get_data_loaders(4, 0, types.SimpleNamespace(lbl_smooth=0.0))
+
+
+def test_native_ingest_line_semantics(pkg, tmp_path):
+    """Whitespace, newline and error behaviour of data_loader.py:61-70 as the Python reader shows it."""
+    ok = 'a  r1\tb\r\nb r2 c\n c\tr1\ta \rd r2 d'                          # mixed separators, \r\n, lone \r, no final newline
+    _write_splits(tmp_path, 'ok', (ok, 'a r1 c\n', 'e r3 a\n'))
+    nat, py = _load_in(pkg, tmp_path, 'ok', True), _load_in(pkg, tmp_path, 'ok', False)
+    assert nat._id_triples is not None
+    assert list(nat.entity2id.items()) == list(py.entity2id.items()) == [('a', 0), ('b', 1), ('c', 2), ('d', 3), ('e', 4)]
+    assert nat.triplets == py.triplets and nat.num_edge == 4
+    _write_splits(tmp_path, 'short', ('a r b\na r\n', 'a r b\n', 'a r b\n'))
+    _write_splits(tmp_path, 'blank', ('a r b\n\na r b\n', 'a r b\n', 'a r b\n'))
+    _write_splits(tmp_path, 'long', ('a r b c\n', 'a r b\n', 'a r b\n'))
+    for name in ('short', 'blank', 'long'):
+        for native in (True, False):
+            with pytest.raises(ValueError):
+                _load_in(pkg, tmp_path, name, native)
+    _write_splits(tmp_path, 'upper', ('a r b\n', 'a r B\n', 'a r b\n'))
+    for native in (True, False):
+        with pytest.raises(KeyError):
+            _load_in(pkg, tmp_path, 'upper', native)
+    _write_splits(tmp_path, 'utf', ('caf\u00e9 r b\n', 'b r caf\u00e9\n', 'b r b\n'))      # declined by the native reader
+    nat = _load_in(pkg, tmp_path, 'utf', True)
+    assert nat._id_triples is None and nat.entity2id == {'caf\u00e9': 0, 'b': 1}
+    (tmp_path / 'data' / 'missing').mkdir()
+    for native in (True, False):
+        with pytest.raises(FileNotFoundError):
+            _load_in(pkg, tmp_path, 'missing', native)
+
+
+def test_native_ingest_random_200k(pkg, tmp_path):
+    """A larger file: ids and query lists of the native reader equal the Python reader's; prints both wall-clocks."""
+    import time
+    rng = np.random.default_rng(5)
+    def lines(n):
+        s, r, o = rng.integers(0, 30000, n), rng.integers(0, 200, n), rng.integers(0, 30000, n)
+        return ''.join('e%d\tr%d\te%d\n' % t for t in zip(s, r, o))
+    _write_splits(tmp_path, 'big', (lines(200000), lines(5000), lines(5000)))
+    t0 = time.perf_counter()
+    nat = _load_in(pkg, tmp_path, 'big', True)
+    t1 = time.perf_counter()
+    py = _load_in(pkg, tmp_path, 'big', False)
+    t2 = time.perf_counter()
+    paths = [str(tmp_path / 'data' / 'big' / (sp + '.txt')) for sp in ('train', 'valid', 'test')]
+    t3 = time.perf_counter()
+    _, _, ids = pkg._native.ingest(*paths)
+    t4 = time.perf_counter()
+    pkg._native.filter_index_build(torch.cat(list(ids.values())), len(nat.relation2id) // 2)
+    t5 = time.perf_counter()
+    scratch = object.__new__(pkg.DataLoader)                  # the two Python passes alone, on a throw-away object
+    scratch.data_dir = str(tmp_path / 'data' / 'big')
+    t6 = time.perf_counter(); scratch._read_ids_python(); t7 = time.perf_counter()
+    t8 = time.perf_counter(); pkg.dist.FilterIndex.from_known(py._known_all, 2 * py.num_relation); t9 = time.perf_counter()
+    print('210k triples: ids native %.3f s vs Python %.3f s; known-answer index native %.3f s vs Python %.3f s; '
+          'whole DataLoader (query lists built in Python in both) %.2f s vs %.2f s'
+          % (t4 - t3, t7 - t6, t5 - t4, t9 - t8, t1 - t0, t2 - t1))
+    assert list(nat.entity2id.items()) == list(py.entity2id.items())
+    assert list(nat.relation2id.items()) == list(py.relation2id.items())
+    assert np.array_equal(nat.graph.edge_index.numpy(), py.graph.edge_index.numpy())
+    assert np.array_equal(nat.graph.edge_attr.numpy(), py.graph.edge_attr.numpy())
+    a, b = nat.filter_index(), py.filter_index()
+    assert torch.equal(a.keys, b.keys) and torch.equal(a.ptr, b.ptr) and torch.equal(a.tails, b.tails)
+
+
 def test_uppercase_token_raises_like_reference(pkg, tmp_path):
     d = tmp_path / 'data' / 'u'
     d.mkdir(parents=True)
