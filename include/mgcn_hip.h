@@ -246,6 +246,15 @@ int mgcn_filter_mask(int32_t batch, const int64_t *qkey_dev, int64_t num_keys, c
                      const int64_t *ptr_dev, const int32_t *tails_dev, int64_t ent_row0, int64_t n_local,
                      uint32_t *mask_dev, int64_t ldm, void *stream);
 
+/* Training targets on the device (SURVEY N2 for the train loop; replaces the per-sample dense label rows of
+ * data_loader.py:34-51 and their host-to-device copy, main.py:62): out_dev[b, n] = hot if entity ent_row0 + n is a known
+ * tail of query b's key, else cold. The caller passes hot = (1 - eps) * 1 + 1/N and cold = (1 - eps) * 0 + 1/N evaluated
+ * in f32 as numpy does (data_loader.py:41-43), or 1 and 0 without smoothing. Index arrays as in mgcn_filter_mask
+ * (built over the TRAIN split). out_dev [batch, ldo >= n_local]. */
+int mgcn_label_rows(int32_t batch, const int64_t *qkey_dev, int64_t num_keys, const int64_t *keys_dev,
+                    const int64_t *ptr_dev, const int32_t *tails_dev, int64_t ent_row0, int64_t n_local, float hot,
+                    float cold, float *out_dev, int64_t ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

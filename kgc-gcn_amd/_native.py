@@ -39,6 +39,7 @@ _SIGNATURES = {
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
                                        _ptr, _i64, _ptr, _ptr]),
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
+    'mgcn_label_rows': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
     'mgcn_ingest_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_ptr)]),
     'mgcn_ingest_close': (None, [_ptr]),
     'mgcn_ingest_count': (_i64, [_ptr, _i32]),
@@ -385,6 +386,29 @@ def filter_mask(qkey, keys, ptr, tails, n_local, ent_row0=0, out=None):
                                   _dev(ptr, torch.int64, 'ptr'), _dev(tails, torch.int32, 'tails'), int(ent_row0),
                                   int(n_local), _dev(out, torch.int32, 'mask'), out.size(1), _stream(qkey)),
            'mgcn_filter_mask')
+    return out
+
+
+def label_rows(qkey, keys, ptr, tails, n_local, lbl_smooth=0.0, num_entities=None, ent_row0=0, out=None):
+    """Dense training targets [B, n_local] f32 for queries with keys `qkey` (see mgcn_label_rows): 1 at the known
+    tails, 0 elsewhere, then (1 - eps) * y + 1/N when eps != 0 (data_loader.py:41-43, evaluated in f32 as numpy does)."""
+    import numpy as np
+    B = qkey.numel()
+    N = int(n_local if num_entities is None else num_entities)
+    y = np.array([1.0, 0.0], dtype=np.float32)
+    if lbl_smooth != 0.0:
+        y = (1.0 - lbl_smooth) * y + (1.0 / N)
+    if out is None:
+        out = torch.empty((B, int(n_local)), dtype=torch.float32, device=qkey.device)
+    if out.size(0) != B or out.size(1) < n_local or out.stride(1) != 1:
+        raise NativeError('label_rows: out must be (%d, >= %d) with unit column stride' % (B, n_local))
+    if ptr.numel() != keys.numel() + 1:
+        raise NativeError('label_rows: ptr must have len(keys) + 1 entries')
+    _same_device(qkey, keys, ptr, tails, out)
+    _check(lib().mgcn_label_rows(B, _dev(qkey, torch.int64, 'qkey'), keys.numel(), _dev(keys, torch.int64, 'keys'),
+                                 _dev(ptr, torch.int64, 'ptr'), _dev(tails, torch.int32, 'tails'), int(ent_row0),
+                                 int(n_local), float(y[0]), float(y[1]), _dev(out, torch.float32, 'labels'),
+                                 out.stride(0), _stream(qkey)), 'mgcn_label_rows')
     return out
 
 

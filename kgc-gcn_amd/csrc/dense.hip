@@ -497,6 +497,32 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(const int64_t *__restr
   }
 }
 
+// Training targets on the device (replaces building the dense [B, N] label block per sample on the host,
+// data_loader.py:34-51, and shipping it over PCIe every step): one workgroup per query fills its row with `cold`
+// and then writes `hot` at the known tails of its (subject, relation) key — (1 - eps) * y + 1/N with y in {0, 1}
+// evaluated on the host exactly as numpy does (data_loader.py:41-43), so the rows are bit-identical.
+__global__ __launch_bounds__(256) void label_rows_kernel(const int64_t *__restrict__ qkey, int batch,
+                                                         const int64_t *__restrict__ keys, int64_t nkeys,
+                                                         const int64_t *__restrict__ ptr, const int32_t *__restrict__ tails,
+                                                         int64_t row0, int64_t n_local, float hot, float cold, float *out,
+                                                         int64_t ldo) {
+  const int q = blockIdx.x;
+  float *row = out + int64_t(q) * ldo;
+  for (int64_t n = threadIdx.x; n < n_local; n += 256) row[n] = cold;
+  const int64_t key = qkey[q];
+  int64_t lo = 0, hi = nkeys;
+  while (lo < hi) {  // block-uniform
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= nkeys || keys[lo] != key) return;
+  __syncthreads();   // the fill above is complete (same workgroup wrote the row)
+  for (int64_t i = ptr[lo] + threadIdx.x; i < ptr[lo + 1]; i += 256) {
+    const int64_t n = int64_t(tails[i]) - row0;
+    if (n >= 0 && n < n_local) row[n] = hot;
+  }
+}
+
 void set_vec_flags(TileArgs *p) {
   p->a_vec = (p->lda % 4 == 0) && mgcn::aligned16(p->a);
   p->b_vec = (p->ldb % 4 == 0) && mgcn::aligned16(p->b);
@@ -592,6 +618,18 @@ extern "C" int mgcn_filter_mask(int32_t batch, const int64_t *qkey_dev, int64_t 
   hipLaunchKernelGGL(filter_mask_kernel, dim3(unsigned((batch + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      qkey_dev, batch, keys_dev, num_keys, ptr_dev, tails_dev, ent_row0, n_local, mask_dev, ldm);
   MGCN_CHECK_LAUNCH("filter_mask_kernel");
+  return MGCN_OK;
+}
+
+extern "C" int mgcn_label_rows(int32_t batch, const int64_t *qkey_dev, int64_t num_keys, const int64_t *keys_dev,
+                               const int64_t *ptr_dev, const int32_t *tails_dev, int64_t ent_row0, int64_t n_local,
+                               float hot, float cold, float *out_dev, int64_t ldo, void *stream) {
+  MGCN_REQUIRE(batch >= 0 && num_keys >= 0 && n_local >= 0 && ent_row0 >= 0 && ldo >= n_local, "label_rows: bad sizes");
+  if (batch == 0) return MGCN_OK;
+  MGCN_REQUIRE(qkey_dev && out_dev && ptr_dev && (num_keys == 0 || (keys_dev && tails_dev)), "label_rows: null pointer");
+  hipLaunchKernelGGL(label_rows_kernel, dim3(unsigned(batch)), dim3(256), 0, static_cast<hipStream_t>(stream), qkey_dev,
+                     batch, keys_dev, num_keys, ptr_dev, tails_dev, ent_row0, n_local, hot, cold, out_dev, ldo);
+  MGCN_CHECK_LAUNCH("label_rows_kernel");
   return MGCN_OK;
 }
 

@@ -165,6 +165,25 @@ class DataLoader(object):
             return FilterIndex(keys, ptr, tails, 2 * self.num_relation)
         return FilterIndex.from_known(self._known_all, 2 * self.num_relation)
 
+    def train_index(self):
+        """Known tails of every (subject, relation) over the TRAIN split, both directions — what the train dataset's
+        label rows mark (data_loader.py:80-83,100-102) — as a dist.FilterIndex for mgcn_label_rows."""
+        from .dist import FilterIndex
+        if self._id_triples is not None:
+            from . import _native
+            keys, ptr, tails = _native.filter_index_build(self._id_triples['train'], self.num_relation)
+            return FilterIndex(keys, ptr, tails, 2 * self.num_relation)
+        known = {q['triple'][:2]: q['label'] for q in self.triplets['train']}
+        return FilterIndex.from_known(known, 2 * self.num_relation)
+
+    def train_queries(self):
+        """[Q, 2] int64 (subject, relation id): the distinct training queries, in the train dataset's order."""
+        if self.triplets is not None:
+            return torch.tensor([q['triple'][:2] for q in self.triplets['train']], dtype=torch.int64).reshape(-1, 2)
+        t = self._id_triples['train']
+        both = torch.cat([t[:, :2], torch.stack([t[:, 2], t[:, 1] + self.num_relation], dim=1)], dim=0)
+        return torch.unique(both, dim=0)
+
     def eval_queries(self, split):
         """[Q, 3] int64 (subject, relation id, object): the split's tail queries followed by its head queries."""
         if self._id_triples is not None:

@@ -33,6 +33,32 @@ def train(model, data_iter, graph, optimizer, params):
     return loss_avg()
 
 
+def train_device_labels(model, queries, index, graph, optimizer, params, batch_size, generator=None):
+    """One epoch like `train`, but the label rows never exist on the host: `queries` [Q, 2] int64
+    (DataLoader.train_queries()), `index` = DataLoader.train_index() on the device; per step only B keys are indexed
+    and mgcn_label_rows writes the smoothed [B, N] targets next to the scores. Shuffles like the reference's loader
+    (data_loader.py:190) with `generator`. Same loss / clipping / optimizer calls as main.py:56-70."""
+    from . import _native
+    model.train()
+    loss_avg = RunningAverage()
+    dev = params.device
+    queries = queries.to(dev)
+    order = torch.randperm(queries.size(0), generator=generator).to(dev)
+    n_ent = model.entity_embedding.size(0)
+    for i in range(0, queries.size(0), batch_size):
+        q = queries.index_select(0, order[i:i + batch_size])
+        optimizer.zero_grad()
+        labels = _native.label_rows(index.query_keys(q[:, 0], q[:, 1]), index.keys, index.ptr, index.tails, n_ent,
+                                    lbl_smooth=params.lbl_smooth)
+        pred = model(q[:, 0], q[:, 1], graph)
+        loss = model.loss(pred, labels)
+        loss.backward()
+        nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=params.clip_grad)
+        optimizer.step()
+        loss_avg.update(loss.item())
+    return loss_avg()
+
+
 def ranks_from_scores(pred, label, obj):
     """main.py:122-126 on a materialised score block."""
     rows = torch.arange(pred.size(0), device=pred.device)

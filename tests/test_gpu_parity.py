@@ -516,3 +516,48 @@ def test_hub_splitting_forward_and_backward(pkg, oracle, case, fused, monkeypatc
                             (rg.grad, osd['relation_embedding'].grad, 'rel')):
         scale = float(want.abs().max()) + 1e-12
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-3, atol=5e-5 * scale + 1e-9, err_msg=name)
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+@pytest.mark.parametrize('smooth', [True, False])
+def test_device_label_rows_equal_loader_rows(pkg, case, smooth):
+    """mgcn_label_rows writes the rows the train dataset builds on the host — bit for bit, label
+    smoothing included (data_loader.py:34-51) — and a row shard is the matching column range."""
+    g = golden(case)
+    dl, params = _loader(pkg, g)
+    if not smooth:
+        params.lbl_smooth = 0.0
+    ds = dl._get_dataset('train', params)
+    want = torch.stack([ds[i][1] for i in range(len(ds))])
+    idx, q = dl.train_index().to(DEV), dl.train_queries().to(DEV)
+    N = dl.num_entity
+    got = pkg._native.label_rows(idx.query_keys(q[:, 0], q[:, 1]), idx.keys, idx.ptr, idx.tails, N, lbl_smooth=params.lbl_smooth)
+    assert torch.equal(got.cpu(), want)
+    lo, hi = N // 3, N - 1
+    part = pkg._native.label_rows(idx.query_keys(q[:, 0], q[:, 1]), idx.keys, idx.ptr, idx.tails, hi - lo,
+                                  lbl_smooth=params.lbl_smooth, num_entities=N, ent_row0=lo)
+    assert torch.equal(part.cpu(), want[:, lo:hi])
+    unknown = pkg._native.label_rows(torch.tensor([10 ** 12], device=DEV), idx.keys, idx.ptr, idx.tails, N)
+    assert float(unknown.abs().sum()) == 0.0
+
+
+def test_train_epoch_with_device_labels(pkg):
+    """harness.train_device_labels: one epoch on syn_b runs through the HIP forward/backward with targets produced on the
+    device; with the loader's own batch it gives the loader loop's loss exactly."""
+    g = golden('syn_b')
+    model, dl, params = _model(pkg, g)
+    params.clip_grad = 1.0
+    idx, q = dl.train_index().to(DEV), dl.train_queries()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss = pkg.harness.train_device_labels(model, q, idx, dl.graph, opt, params, batch_size=16,
+                                           generator=torch.Generator().manual_seed(0))
+    assert np.isfinite(loss) and 0.0 < loss < 1.0
+    ds = dl._get_dataset('train', params)
+    trip = torch.stack([ds[i][0] for i in range(8)]).to(DEV)
+    lab_host = torch.stack([ds[i][1] for i in range(8)]).to(DEV)
+    lab_dev = pkg._native.label_rows(idx.query_keys(trip[:, 0], trip[:, 1]), idx.keys, idx.ptr, idx.tails, dl.num_entity,
+                                     lbl_smooth=params.lbl_smooth)
+    model.eval()
+    with torch.no_grad():
+        pred = model(trip[:, 0], trip[:, 1], dl.graph)
+        assert float(model.loss(pred, lab_host)) == float(model.loss(pred, lab_dev))

@@ -249,6 +249,30 @@ def test_ingest_only_loader(pkg):
         lean.get_data_loaders(4, 0, types.SimpleNamespace(lbl_smooth=0.0))
 
 
+@pytest.mark.parametrize('case', ['toy_small', 'syn_b'])
+def test_train_index_and_queries(pkg, case):
+    """N2 for training, host side: the train-split index marks exactly the train dataset's label sets, from either reader."""
+    g = golden(case)
+    root, name = os.path.dirname(os.path.dirname(g.data_dir)), os.path.basename(g.data_dir)
+    for native in (True, False):
+        dl = _load_in(pkg, root, name, native)
+        idx, q = dl.train_index(), dl.train_queries()
+        assert q.shape == (len(dl.triplets['train']), 2)
+        keys = idx.query_keys(q[:, 0], q[:, 1])
+        pos = torch.searchsorted(idx.keys, keys)
+        assert torch.equal(idx.keys[pos], keys)
+        for i, item in enumerate(dl.triplets['train']):
+            lo, hi = int(idx.ptr[pos[i]]), int(idx.ptr[pos[i] + 1])
+            assert idx.tails[lo:hi].tolist() == sorted(item['label'])
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        lean = pkg.DataLoader(name, types.SimpleNamespace(lbl_smooth=0.0, ingest_only=True))
+    finally:
+        os.chdir(cwd)
+    assert sorted(map(tuple, lean.train_queries().tolist())) == sorted(map(tuple, q.tolist()))
+
+
 def test_native_ingest_line_semantics(pkg, tmp_path):
     """Whitespace, newline and error behaviour of data_loader.py:61-70 as the Python reader shows it."""
     ok = 'a  r1\tb\r\nb r2 c\n c\tr1\ta \rd r2 d'                          # mixed separators, \r\n, lone \r, no final newline

@@ -83,6 +83,29 @@ def main():
         timed('clip', lambda: torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=params.clip_grad))
         timed('adam', opt.step)
     print('%s  layers %d  batch %d: %.3f ms per training step (loss %.5f)' % (args.shape, args.layers, B, total * 1e3, float(loss)))
+    # target rows: what the reference's loader does per step (per-sample numpy rows, stack, host-to-device copy of
+    # [B, N] f32, data_loader.py:34-51 + main.py:62) against mgcn_label_rows on the device
+    import numpy as np
+    known = {}
+    for s_, r_ in trip.tolist():
+        known.setdefault((s_, r_), set()).update(int(v) for v in torch.randint(0, N, (4,), generator=g))
+    index = pkg.dist.FilterIndex.from_known(known, 2 * R).to(dev)
+    items = [{'triple': (s_, r_, -1), 'label': sorted(known[(s_, r_)])} for s_, r_ in trip.tolist()]
+    ds = pkg.data_loader.KBDataset(items, N, params, training=True)
+    def host_rows():
+        batch = ds.collate_fn([ds[i] for i in range(B)])
+        return batch[1].to(dev)
+    def device_rows():
+        return pkg._native.label_rows(index.query_keys(trip[:, 0], trip[:, 1]), index.keys, index.ptr, index.tails, N,
+                                      lbl_smooth=params.lbl_smooth)
+    for name, fn in (('host rows + copy', host_rows), ('mgcn_label_rows', device_rows)):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out = fn()
+        torch.cuda.synchronize()
+        print('  targets for one step, %-18s %.3f ms' % (name + ':', (time.perf_counter() - t0) / 10 * 1e3))
+    assert torch.equal(host_rows(), device_rows())
     print('  phases (synchronised): ' + '  '.join('%s %.3f ms' % (k, v / args.steps * 1e3) for k, v in marks.items()))
 
 
