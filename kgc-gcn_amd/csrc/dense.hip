@@ -238,8 +238,16 @@ struct BDma {
   }
 };
 
+// Register budget per instantiation (waves per SIMD the compiler must leave room for). At five waves per SIMD (96
+// VGPRs) the wide instantiations spilled: 6-62 registers for the 13-tile dense / scoring kernels, 12-195 for RANK,
+// which carries three counters per column tile next to the accumulators (the one-shot evaluation ran 16 % slower
+// for it). Every instantiation now compiles spill-free.
+constexpr int min_waves(int epi, int nt) {
+  return epi == EPI_RANK ? (nt >= 13 ? 2 : nt >= 8 ? 3 : 5) : (nt >= 13 ? 3 : nt >= 8 ? 4 : 5);
+}
+
 template <int EPI, bool B_NT, int NT, bool FAST>
-__global__ __launch_bounds__(THREADS, 5) void tile_kernel(TileArgs p) {
+__global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileArgs p) {
   using Stage = BStage<B_NT, NT, FAST>;
   using Dma = BDma<NT>;
   constexpr bool DMA = FAST && !B_NT;
