@@ -96,8 +96,8 @@ def encode_sharded(model, graph, group=None):
     csr = graph.csr(model.relation_embedding.size(0) + 1)
     model._use_slot_order(csr)
     N = csr.num_nodes
-    b = shard_bounds(N, world)
-    n0, n1, chunk = b[rank], b[rank + 1], (N + world - 1) // world
+    b = csr.balanced_bounds(world)          # equal work (slots + nodes) per rank, not equal node counts (degree skew)
+    n0, n1, chunk = b[rank], b[rank + 1], max(b[r + 1] - b[r] for r in range(world))
     x, rel = model.entity_embedding.detach(), model.relation_embedding.detach()
     tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
     ee_sub = csr.shard_ee_sub(n0, n1)
@@ -111,8 +111,11 @@ def encode_sharded(model, graph, group=None):
                                 bn.running_var, bn.weight, bn.bias, bn.eps, local[:n1 - n0], node_range=(n0, n1),
                                 ee_sub=ee_sub)
         full = torch.empty((world * chunk, layer.out_channels), dtype=torch.float32, device=x.device)
-        dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal row chunks, gathered in place
-        x = full[:N]
+        dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal (padded) chunks, gathered in place
+        if all(b[r + 1] - b[r] == chunk for r in range(world - 1)):
+            x = full[:N]
+        else:                                                                  # drop each rank's padding rows
+            x = torch.cat([full[r * chunk:r * chunk + b[r + 1] - b[r]] for r in range(world)], dim=0)
         rel = _native.matmul(rel.contiguous(), layer.rels_weight)
     return x, rel
 

@@ -73,6 +73,36 @@ class GraphCSR(object):
             return 0, 0
         return self._chunkptr[int(n0)], self._chunkptr[int(n1)]
 
+    def balanced_bounds(self, world, node_weight=1.0, align=32):
+        """Destination ranges with (about) equal WORK instead of equal node counts ("balance the ranges by
+        edge count"): work(n) = slots of n in both halves, hub slots included, + node_weight (the self-loop message and
+        the output row). Boundaries are rounded to multiples of `align` (the fused kernel's tile height). Returns
+        W + 1 non-decreasing bounds from 0 to N."""
+        N, W = self.num_nodes, int(world)
+        key = ('balanced', W, float(node_weight), int(align))
+        cache = self.__dict__.setdefault('_shard_cache', {})
+        if key not in cache:
+            rp = self.rowptr.cpu().to(torch.int64)
+            work = (rp[0, 1:] - rp[0, :-1]) + (rp[1, 1:] - rp[1, :-1])
+            if self.num_chunks:
+                ch = self.chunks.cpu().to(torch.int64)
+                hub = self.hubinfo.cpu().to(torch.int64)                       # [2, N, 2] (first chunk, count)
+                first, cnt = hub[:, :, 0], hub[:, :, 1]
+                has = cnt > 0
+                beg = ch[first.clamp(min=0), 0]
+                end = ch[(first + cnt - 1).clamp(min=0), 1]
+                work = work + torch.where(has, end - beg, torch.zeros_like(beg)).sum(0)
+            prefix = torch.cat([work.new_zeros(1), torch.cumsum(work.double() + node_weight, 0)])
+            total = float(prefix[-1])
+            bounds = [0]
+            for r in range(1, W):
+                cut = int(torch.searchsorted(prefix, torch.tensor(total * r / W, dtype=prefix.dtype)))
+                cut = min(N, max(bounds[-1], (cut + align // 2) // align * align))
+                bounds.append(cut)
+            bounds.append(N)
+            cache[key] = bounds
+        return list(cache[key])
+
     def shard_slot_counts(self, n0, n1):
         (i0, i1), (o0, o1), (h0, h1) = self._shard_bounds(n0, n1)
         return i1 - i0, o1 - o0, h1 - h0

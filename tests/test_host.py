@@ -123,6 +123,27 @@ def test_destination_shards_with_hubs(pkg):
     assert chunks_seen == csr.num_chunks
 
 
+@pytest.mark.parametrize('thr', [0, 8])
+def test_balanced_destination_bounds(pkg, thr):
+    """ranges balanced by work (slots, hub slots included, + nodes), not by node count."""
+    g = golden('syn_c')                                                     # the skewed golden graph (max degree 409)
+    ei, et = g.t('dl_edge_index'), g.t('dl_edge_attr')[0]
+    N, R = int(g['dl_num_entity']), int(g['dl_num_relation'])
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, et, 'cpu', hub_threshold=thr, hub_chunk=5)
+    dst = csr.slot_dst & 0x7fffffff
+    def spread(b):
+        work = [int(((dst >= b[r]) & (dst < b[r + 1])).sum()) + (b[r + 1] - b[r]) for r in range(len(b) - 1)]
+        return max(work) / (sum(work) / len(work))
+    for W in (1, 2, 3):
+        b = csr.balanced_bounds(W, align=4)
+        assert b[0] == 0 and b[-1] == N and len(b) == W + 1 and all(x <= y for x, y in zip(b, b[1:]))
+        assert all(x % 4 == 0 for x in b[1:-1])
+        if W > 1:
+            assert spread(b) < 1.05 < spread(pkg.dist.shard_bounds(N, W))
+    assert csr.balanced_bounds(3, align=4) == pkg.GraphCSR(N, 2 * R + 1, ei, et, 'cpu', hub_threshold=8 - thr,
+                                                          hub_chunk=5).balanced_bounds(3, align=4)
+
+
 def test_feeder_rejects_bad_input(pkg):
     ei = torch.tensor([[0, 5], [1, 0]])
     with pytest.raises(pkg._native.NativeError, match='outside'):
