@@ -238,6 +238,23 @@ int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t di
                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
                     const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
 
+/* Training loss fused with the scoring pass (replaces model.py:177-179 + model.py:42-44 and the
+ * autograd of both down to the logits, main.py:61-66): for z[b, n] = x[b,:] . ent[n,:] + bias[n], p = sigmoid(z) and
+ * targets y[b, n] = hot where bit n of mask[b] is set, cold elsewhere (mgcn_filter_mask over the TRAIN index; hot / cold
+ * as in mgcn_label_rows), ONE launch writes
+ *   grad_logit_dev [n_local, ldg] (row = entity, column = query): d mean-BCE / d z = (p - y) / max(p(1-p), 1e-12) * p(1-p)
+ *                  * inv_count — torch's BCELoss and sigmoid backward formulas multiplied out, inv_count = 1 / (B * N);
+ *   loss_partial_dev [mgcn_score_bce_partials(batch, n_local)]: per-workgroup sums of
+ *                  (y - 1) * max(log1p(-p), -100) - y * max(log(p), -100), reduced in a fixed order; the loss is their
+ *                  sum * inv_count.
+ * Neither the scores nor the [B, N] targets are materialised. The caller finishes the backward with plain GEMMs:
+ * d ent = G @ x (mgcn_matmul_f32), d x = G^T @ ent, d bias = row sums of G. Returns MGCN_EUNSUPPORTED unless operands
+ * are 16-byte aligned, dim % 4 == 0 and batch % 4 == 0 (callers then use mgcn_score_fwd + the framework's loss). */
+int64_t mgcn_score_bce_partials(int32_t batch, int64_t n_local);
+int mgcn_score_bce_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx, const float *ent_dev,
+                       int64_t lde, const float *bias_dev, const uint32_t *mask_dev, int64_t ldm, float hot, float cold,
+                       float inv_count, float *grad_logit_dev, int64_t ldg, float *loss_partial_dev, void *stream);
+
 /* Filter bits on the device (replaces building + shipping the dense [B, N] label block of data_loader.py:34-51
  * for evaluation). keys_dev [num_keys] sorted int64 (subject * num_rel_ids + relation), ptr_dev
  * [num_keys+1], tails_dev [ptr[num_keys]] int32: the known tails of each (subject, relation). For query b with key

@@ -39,6 +39,9 @@ _SIGNATURES = {
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
                                        _ptr, _i64, _ptr, _ptr]),
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
+    'mgcn_score_bce_partials': (_i64, [_i32, _i64]),
+    'mgcn_score_bce_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr,
+                                          _i64, _ptr, _ptr]),
     'mgcn_label_rows': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
     'mgcn_ingest_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_ptr)]),
     'mgcn_ingest_close': (None, [_ptr]),
@@ -389,15 +392,42 @@ def filter_mask(qkey, keys, ptr, tails, n_local, ent_row0=0, out=None):
     return out
 
 
+def smoothed_targets(lbl_smooth, num_entities):
+    """(hot, cold) = (1 - eps) * y + 1/N for y = 1, 0, evaluated in f32 as numpy does (data_loader.py:41-43)."""
+    import numpy as np
+    y = np.array([1.0, 0.0], dtype=np.float32)
+    if lbl_smooth != 0.0:
+        y = (1.0 - lbl_smooth) * y + (1.0 / int(num_entities))
+    return float(y[0]), float(y[1])
+
+
+def score_bce_supported(x, ent):
+    return (x.size(0) % 4 == 0 and x.size(1) % 4 == 0 and x.is_contiguous() and ent.is_contiguous()
+            and x.data_ptr() % 16 == 0 and ent.data_ptr() % 16 == 0)
+
+
+def score_bce_fwd(x, ent, bias, mask, hot, cold):
+    """(N3) One launch: returns (loss [] f32, G [n, B] f32 = d loss / d logits, entity-major) for the mean BCE of
+    sigmoid(x @ ent^T + bias) against targets `hot` at the mask's bits, `cold` elsewhere (see mgcn_score_bce_fwd)."""
+    B, n, O = _score_args(x, ent, bias)
+    if mask.dim() != 2 or mask.size(0) != B or mask.size(1) < (n + 31) // 32 or not mask.is_contiguous():
+        raise NativeError('score_bce_fwd: mask must be contiguous (%d, >= %d)' % (B, (n + 31) // 32))
+    _same_device(x, ent, bias, mask)
+    g = torch.empty((n, B), dtype=torch.float32, device=x.device)
+    parts = torch.empty(int(lib().mgcn_score_bce_partials(B, n)), dtype=torch.float32, device=x.device)
+    inv = 1.0 / (float(B) * float(n))
+    _check(lib().mgcn_score_bce_fwd(B, n, O, _dev(x, torch.float32, 'x'), _ld(x), _dev(ent, torch.float32, 'ent'), _ld(ent),
+                                    _dev(bias, torch.float32, 'bias'), _dev(mask, torch.int32, 'mask'), mask.size(1),
+                                    float(hot), float(cold), inv, _dev(g, torch.float32, 'grad_logit'), g.stride(0),
+                                    _dev(parts, torch.float32, 'loss_partial'), _stream(x)), 'mgcn_score_bce_fwd')
+    return parts.sum() * inv, g
+
+
 def label_rows(qkey, keys, ptr, tails, n_local, lbl_smooth=0.0, num_entities=None, ent_row0=0, out=None):
     """Dense training targets [B, n_local] f32 for queries with keys `qkey` (see mgcn_label_rows): 1 at the known
     tails, 0 elsewhere, then (1 - eps) * y + 1/N when eps != 0 (data_loader.py:41-43, evaluated in f32 as numpy does)."""
-    import numpy as np
     B = qkey.numel()
-    N = int(n_local if num_entities is None else num_entities)
-    y = np.array([1.0, 0.0], dtype=np.float32)
-    if lbl_smooth != 0.0:
-        y = (1.0 - lbl_smooth) * y + (1.0 / N)
+    y = smoothed_targets(lbl_smooth, int(n_local if num_entities is None else num_entities))
     if out is None:
         out = torch.empty((B, int(n_local)), dtype=torch.float32, device=qkey.device)
     if out.size(0) != B or out.size(1) < n_local or out.stride(1) != 1:

@@ -5,6 +5,7 @@
 //   EPI_SIGMOID   score[b, n] = sigmoid(ent[n,:] . x[b,:] + bias[n])        (model.py:177-179)
 //   EPI_TARGET    target[b]   = score[b, obj[b]]  (same tile arithmetic, gathered rows, diagonal)
 //   EPI_RANK      filtered counts gt / ties_lower / ties per query, scores never stored (main.py:122-126)
+//   EPI_BCE       training: BCE(sigmoid(score), target) partial sums + d loss / d logit [M, ncols] (main.py:61-66, N3)
 //
 // Geometry. The streamed operand (aggregates [N,3D], or the entity table [N,O]) is always the MFMA A
 // operand and goes global -> registers directly: lane (r = l&15, q = l>>4) loads the 16 bytes
@@ -26,7 +27,7 @@
 
 namespace {
 
-enum { EPI_NONE = 0, EPI_BN_TANH = 1, EPI_SIGMOID = 2, EPI_TARGET = 3, EPI_RANK = 4 };
+enum { EPI_NONE = 0, EPI_BN_TANH = 1, EPI_SIGMOID = 2, EPI_TARGET = 3, EPI_RANK = 4, EPI_BCE = 5 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,6 +43,8 @@ struct TileArgs {
   const float *label;    // RANK: [ncols, ldl] dense 0/1 rows, or
   const uint32_t *mask;  // RANK: [ncols, ldl] words, bit (n & 31) of word n >> 5 set = entity n filtered
   unsigned long long *counts;  // RANK: [ncols, 3]
+  float *loss_partial;   // BCE: one partial sum per block
+  float hot, cold, inv_count;  // BCE: target values at / off the known tails, 1 / (B * N)
   int64_t lda, ldb, ldc, ldl, m, row0, n_local;
   int32_t k, ncols, tiles_m;
   int32_t a_vec, b_vec;  // 16-byte loads allowed (alignment + leading dimension checked on the host)
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
   constexpr int SLAB_F = DMA ? Dma::SLAB_F : KS * LDB;
   // ONE shared array (slabs, output staging, RANK counters): a second __shared__ object next to an LDS-DMA
   // target makes hipcc drain vmcnt before every ds_read (cdna_hip_programming.md, M = 256 GEMM item 4a).
-  __shared__ __attribute__((aligned(16))) float Bs[2 * SLAB_F + (EPI == EPI_RANK ? BNC * 3 : 0)];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * SLAB_F + (EPI == EPI_RANK ? BNC * 3 : (EPI == EPI_BCE ? 4 : 0))];
   static_assert(2 * KS == BM, "the output staging tile [BM][LDB] reuses the two slab buffers");
   unsigned int *cnt = reinterpret_cast<unsigned int *>(Bs + 2 * SLAB_F);
 
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
   if (EPI == EPI_RANK) {
     for (int i = tid; i < BNC * 3; i += THREADS) cnt[i] = 0;
   }
+  float bce_sum = 0.f;
   unsigned int my_gt[NTW], my_tl[NTW], my_ti[NTW];
   if (EPI == EPI_RANK) {
 #pragma unroll
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
     // Row-major outputs (NONE, BN_TANH) are staged through the (now idle) slab buffers so that every lane
     // stores 16 contiguous bytes of one output row: a dword-per-lane store of the accumulator layout touches
     // 64-byte pieces of four rows per instruction and made the store tail the longest phase of the kernel.
-    constexpr bool STAGED = FAST && (EPI == EPI_NONE || EPI == EPI_BN_TANH);
+    constexpr bool STAGED = FAST && (EPI == EPI_NONE || EPI == EPI_BN_TANH || EPI == EPI_BCE);
     float *os = Bs;  // [BM][LDB]; 2*KS*LDB == BM*LDB floats
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -393,6 +397,17 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
             const int64_t o = p.obj[row] - p.row0;
             if (o >= 0 && o < p.n_local) p.target_out[row] = sigmoidf_(v + p.bias[o]);
           }
+        } else if (EPI == EPI_BCE) {
+          // torch's BCELoss on sigmoid outputs (main.py:62): loss = -(y log p + (1-y) log(1-p)), logs clamped at -100;
+          // d loss / d logit = (p - y) / max(p (1-p), 1e-12) * p (1-p) / (B N), the product of its BCE and sigmoid
+          // backward formulas. y = hot at the known tails of the query (bit mask), cold elsewhere (label smoothing).
+          const float pz = sigmoidf_(v + p.bias[row]);
+          const bool pos = (p.mask[int64_t(col) * p.ldl + (row >> 5)] >> (row & 31)) & 1u;
+          const float y = pos ? p.hot : p.cold;
+          bce_sum += (y - 1.0f) * fmaxf(log1pf(-pz), -100.0f) - y * fmaxf(logf(pz), -100.0f);
+          const float pq = (1.0f - pz) * pz;
+          const float gz = (pz - y) / fmaxf(pq, 1e-12f) * pq * p.inv_count;
+          if (STAGED) os[lrow * LDB + lcol] = gz; else p.c[row * p.ldc + col] = gz;
         } else if (EPI == EPI_RANK) {
           if (row == ob) continue;                                       // the target itself (main.py:125)
           if (p.mask) {                                                    // bit-packed filter (uniform branch)
@@ -428,6 +443,16 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
     }
   }
 
+  if (EPI == EPI_BCE) {   // fixed-order reduction: lanes (xor tree), then the four waves in wave order
+    float v = bce_sum;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    float *wsum = Bs + 2 * SLAB_F;
+    __syncthreads();
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid == 0) p.loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  }
   if (EPI == EPI_RANK) {
     // lanes fr, fr+16, fr+32, fr+48 hold the same query column: fold, then one LDS add per wave
 #pragma unroll
@@ -655,6 +680,35 @@ extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const
   p.bias = bias_dev;
   p.m = n_local; p.k = dim; p.ncols = batch;
   return launch<EPI_SIGMOID, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<SIGMOID>");
+}
+
+extern "C" int64_t mgcn_score_bce_partials(int32_t batch, int64_t n_local) {
+  if (batch <= 0 || n_local <= 0) return 0;
+  const int64_t tiles_m = (n_local + BM - 1) / BM;
+  const int nt = pick_nt(batch);
+  return tiles_m * ((batch + nt * 16 - 1) / (nt * 16));
+}
+
+extern "C" int mgcn_score_bce_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx,
+                                  const float *ent_dev, int64_t lde, const float *bias_dev, const uint32_t *mask_dev,
+                                  int64_t ldm, float hot, float cold, float inv_count, float *grad_logit_dev, int64_t ldg,
+                                  float *loss_partial_dev, void *stream) {
+  if (int rc = check_common("score_bce_fwd", n_local, dim, batch)) return rc;
+  MGCN_REQUIRE(x_dev && ent_dev && bias_dev && mask_dev && grad_logit_dev && loss_partial_dev, "score_bce_fwd: null pointer");
+  MGCN_REQUIRE(ldx >= dim && lde >= dim && ldg >= batch && ldm >= (n_local + 31) / 32, "score_bce_fwd: leading dimension too small");
+  if (batch == 0 || n_local == 0) return MGCN_OK;
+  TileArgs p = {};
+  p.a = ent_dev; p.lda = lde;
+  p.b = x_dev; p.ldb = ldx;
+  p.c = grad_logit_dev; p.ldc = ldg;
+  p.bias = bias_dev; p.mask = mask_dev; p.ldl = ldm;
+  p.hot = hot; p.cold = cold; p.inv_count = inv_count; p.loss_partial = loss_partial_dev;
+  p.m = n_local; p.k = dim; p.ncols = batch;
+  // the partial-sum count handed to the caller assumes the aligned (FAST) tiling: refuse other shapes
+  if (!(mgcn::aligned16(ent_dev) && mgcn::aligned16(x_dev) && mgcn::aligned16(grad_logit_dev) && lde % 4 == 0 &&
+        ldx % 4 == 0 && ldg % 4 == 0 && dim % 4 == 0 && batch % 4 == 0))
+    return mgcn::fail(MGCN_EUNSUPPORTED, "score_bce_fwd: needs 16-byte aligned operands, dim %% 4 == 0 and batch %% 4 == 0");
+  return launch<EPI_BCE, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<BCE>");
 }
 
 extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,

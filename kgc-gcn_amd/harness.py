@@ -33,7 +33,7 @@ def train(model, data_iter, graph, optimizer, params):
     return loss_avg()
 
 
-def train_device_labels(model, queries, index, graph, optimizer, params, batch_size, generator=None):
+def train_device_labels(model, queries, index, graph, optimizer, params, batch_size, generator=None, fused_loss=True):
     """One epoch like `train`, but the label rows never exist on the host: `queries` [Q, 2] int64
     (DataLoader.train_queries()), `index` = DataLoader.train_index() on the device; per step only B keys are indexed
     and mgcn_label_rows writes the smoothed [B, N] targets next to the scores. Shuffles like the reference's loader
@@ -48,10 +48,12 @@ def train_device_labels(model, queries, index, graph, optimizer, params, batch_s
     for i in range(0, queries.size(0), batch_size):
         q = queries.index_select(0, order[i:i + batch_size])
         optimizer.zero_grad()
-        labels = _native.label_rows(index.query_keys(q[:, 0], q[:, 1]), index.keys, index.ptr, index.tails, n_ent,
-                                    lbl_smooth=params.lbl_smooth)
-        pred = model(q[:, 0], q[:, 1], graph)
-        loss = model.loss(pred, labels)
+        if fused_loss:                                   # scores, targets and loss in one launch
+            loss = model.forward_loss(q[:, 0], q[:, 1], graph, index, lbl_smooth=params.lbl_smooth)
+        else:
+            labels = _native.label_rows(index.query_keys(q[:, 0], q[:, 1]), index.keys, index.ptr, index.tails, n_ent,
+                                        lbl_smooth=params.lbl_smooth)
+            loss = model.loss(model(q[:, 0], q[:, 1], graph), labels)
         loss.backward()
         nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=params.clip_grad)
         optimizer.step()

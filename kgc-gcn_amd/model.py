@@ -62,6 +62,24 @@ class _ScoreFn(torch.autograd.Function):
                 gz.sum(0) if ctx.needs_input_grad[2] else None)
 
 
+class _ScoreBCEFn(torch.autograd.Function):
+    """mean BCE(sigmoid(x @ ent^T + bias), targets) in ONE launch: the scores and the [B, N] targets are
+    never materialised; the launch leaves d loss / d logits [N, B], the backward is two plain GEMMs and a row sum."""
+
+    @staticmethod
+    def forward(ctx, x, ent, bias, mask, hot, cold):
+        loss, g = _native.score_bce_fwd(x, ent, bias, mask, hot, cold)
+        ctx.save_for_backward(x, ent, g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, ent, g = ctx.saved_tensors
+        return ((g.t() @ ent) * gl if ctx.needs_input_grad[0] else None,
+                _native.matmul(g, x) * gl if ctx.needs_input_grad[1] else None,
+                g.sum(1) * gl if ctx.needs_input_grad[2] else None, None, None, None)
+
+
 class MGCNConv(nn.Module):
     """One relational layer (model.py:47-127). Parameter names are the reference's."""
 
@@ -383,6 +401,23 @@ class MGCN(nn.Module):
 
     def loss(self, pred, label):
         return self.loss_fn(pred, label)
+
+    def forward_loss(self, src, rel, data, index, lbl_smooth=0.0):
+        """loss(forward(src, rel, data), labels) of main.py:61-62 without the [B, N] scores and labels (SURVEY N2 + N3):
+        `index` is DataLoader.train_index() on the device; the targets are 1 at the known tails of (src, rel), 0
+        elsewhere, smoothed as data_loader.py:41-43. Falls back to the two-step form for batch sizes the fused launch
+        does not take (B % 4 != 0)."""
+        all_ent, all_rel = self.encode(data)
+        x = self.conv2.trunk(torch.index_select(all_ent, 0, src), torch.index_select(all_rel, 0, rel))
+        n_ent = all_ent.size(0)
+        keys = index.query_keys(src, rel)
+        ent = all_ent.contiguous()
+        if x.is_cuda and _native.score_bce_supported(x, ent):
+            hot, cold = _native.smoothed_targets(lbl_smooth, n_ent)
+            mask = _native.filter_mask(keys, index.keys, index.ptr, index.tails, n_ent)
+            return _ScoreBCEFn.apply(x, ent, self.conv2.bias, mask, hot, cold)
+        labels = _native.label_rows(keys, index.keys, index.ptr, index.tails, n_ent, lbl_smooth=lbl_smooth)
+        return self.loss_fn(_ScoreFn.apply(x, ent, self.conv2.bias), labels)
 
     # -- fused evaluation path (main.py:121-126 without materialising [B, N] scores) -------------
     @torch.no_grad()

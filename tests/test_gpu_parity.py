@@ -561,3 +561,59 @@ def test_train_epoch_with_device_labels(pkg):
     with torch.no_grad():
         pred = model(trip[:, 0], trip[:, 1], dl.graph)
         assert float(model.loss(pred, lab_host)) == float(model.loss(pred, lab_dev))
+
+
+@pytest.mark.parametrize('case', FULL_CASES)
+def test_fused_bce_step_vs_golden(pkg, case):
+    """model.forward_loss (scores + targets + BCE + d loss / d logits in one launch, backward by GEMMs)
+    reproduces the reference's training step — loss and the gradient of every parameter (main.py:59-66, dropout 0 /
+    lbl_smooth 0 as in the golden), with the same tolerances as the unfused path."""
+    g = golden(case)
+    model, dl, params = _model(pkg, g, gcn_drop=0.0, hidden_drop=0.0, feat_drop=0.0)
+    model.conv1.drop.p = 0.0
+    model.train()
+    trip, lab = g.t('train_triple').to(DEV), g.t('train_label')
+    idx = dl.train_index().to(DEV)
+    got_lab = pkg._native.label_rows(idx.query_keys(trip[:, 0], trip[:, 1]), idx.keys, idx.ptr, idx.tails, dl.num_entity)
+    assert torch.equal(got_lab.cpu(), lab)                       # the golden batch's targets are the train index's
+    loss = model.forward_loss(trip[:, 0], trip[:, 1], dl.graph, idx, lbl_smooth=0.0)
+    assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-5
+    loss.backward()
+    inv = model._slot_csr.inv_perm
+    for k, ref in g.grads().items():
+        p = dict(model.named_parameters())[k]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        if k == 'edge_embeddings':
+            got = got.index_select(0, inv)
+        scale = float(ref.abs().max()) + 1e-12
+        floor = 2e-6 if k.startswith('conv2.') else 1e-9
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-5 * scale + floor, err_msg=k)
+
+
+@pytest.mark.parametrize('smooth', [0.0, 0.1])
+def test_fused_bce_equals_two_step_loss(pkg, smooth):
+    """The fused launch against score_fwd + label_rows + torch BCELoss on the same operands: loss to 1e-6, d/dx, d/dent,
+    d/dbias to 1e-5 relative — including saturated scores (|logit| up to ~40: the -100 clamp and the 1e-12 floor)."""
+    nat = pkg._native
+    g = torch.Generator().manual_seed(11)
+    B, N, O = 32, 1000, 200
+    x = torch.randn(B, O, generator=g).to(DEV).requires_grad_(True)
+    ent = (torch.randn(N, O, generator=g) * torch.linspace(0.05, 3.0, N).unsqueeze(1)).to(DEV).requires_grad_(True)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    known = {(b, 0): set(torch.randint(0, N, (5,), generator=g).tolist()) for b in range(B)}
+    idx = pkg.dist.FilterIndex.from_known(known, 1).to(DEV)
+    keys = idx.query_keys(torch.arange(B, device=DEV), torch.zeros(B, dtype=torch.int64, device=DEV))
+    hot, cold = nat.smoothed_targets(smooth, N)
+    mask = nat.filter_mask(keys, idx.keys, idx.ptr, idx.tails, N)
+    loss = pkg.model._ScoreBCEFn.apply(x, ent, bias, mask, hot, cold)
+    loss.backward()
+    got = (float(loss.detach()), x.grad.clone(), ent.grad.clone(), bias.grad.clone())
+    for t in (x, ent, bias):
+        t.grad = None
+    labels = nat.label_rows(keys, idx.keys, idx.ptr, idx.tails, N, lbl_smooth=smooth)
+    ref = torch.nn.BCELoss()(pkg.model._ScoreFn.apply(x, ent, bias), labels)
+    ref.backward()
+    assert abs(got[0] - float(ref.detach())) < 1e-6 * max(1.0, abs(float(ref.detach())))
+    for a, b, name in ((got[1], x.grad, 'x'), (got[2], ent.grad, 'ent'), (got[3], bias.grad, 'bias')):
+        scale = float(b.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, err_msg=name)

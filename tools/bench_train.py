@@ -106,6 +106,32 @@ def main():
         torch.cuda.synchronize()
         print('  targets for one step, %-18s %.3f ms' % (name + ':', (time.perf_counter() - t0) / 10 * 1e3))
     assert torch.equal(host_rows(), device_rows())
+    # the same step with scores + targets + BCE + d loss / d logits in one launch (model.forward_loss)
+    def fused_step():
+        model.train()
+        opt.zero_grad()
+        loss = model.forward_loss(trip[:, 0], trip[:, 1], graph, index, lbl_smooth=params.lbl_smooth)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=params.clip_grad)
+        opt.step()
+        return loss
+    def two_step():
+        model.train()
+        opt.zero_grad()
+        loss = model.loss(model(trip[:, 0], trip[:, 1], graph), device_rows())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(parameters=model.parameters(), max_norm=params.clip_grad)
+        opt.step()
+        return loss
+    for name, fn in (('label_rows + forward + BCELoss', two_step), ('forward_loss (fused)', fused_step)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            l = fn()
+        torch.cuda.synchronize()
+        print('  training step, %-32s %.3f ms (loss %.5f)' % (name + ':', (time.perf_counter() - t0) / args.steps * 1e3, float(l)))
     print('  phases (synchronised): ' + '  '.join('%s %.3f ms' % (k, v / args.steps * 1e3) for k, v in marks.items()))
 
 
