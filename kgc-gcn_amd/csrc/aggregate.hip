@@ -692,7 +692,12 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
 #define MGCN_FWD_CASE(V_, C_, U_) hipLaunchKernelGGL((agg_fwd_kernel<V_, C_, U_>), dim3(grid), dim3(256), 0, st, p, g.gs_log2)
     if (g.vec == 4) {
       switch (g.cpl) {
-        case 1: MGCN_FWD_CASE(4, 1, 4); break;
+        case 1:
+          // slots in flight per lane group: short runs (WN18RR: 2.1 slots per destination and half) are covered by
+          // two, and the 58-register build runs eight waves per SIMD instead of five — measured 43 / 68 us against
+          // 46 / 78 us per WN18RR layer; long runs (FB15k-237: 18.7) keep four (83 / 139 us against 86 / 142)
+          if (num_edges_half < 4 * num_nodes) { MGCN_FWD_CASE(4, 1, 2); } else { MGCN_FWD_CASE(4, 1, 4); }
+          break;
         case 2: MGCN_FWD_CASE(4, 2, 2); break;
         case 4: MGCN_FWD_CASE(4, 4, 1); break;
         default: MGCN_FWD_CASE(4, 8, 1); break;
