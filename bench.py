@@ -236,7 +236,30 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
             kern['layer%d' % (li + 1)] = {'us': ta + td, 'algorithmic_bytes': lb,
                                           'hbm_frac': lb / (ta + td) / 1e3 / HBM_PEAK_GBS}
         kern['relproj_l%d' % (li + 1)] = {'us': times['relproj_l%d' % (li + 1)]}
-    cand = {k: v for k, v in kern.items() if not k.startswith(('relproj', 'layer1', 'layer2'))}
+    if fused:
+        # the HBM-bound part on its own: the aggregation launch of the unfused path (what training's forward and
+        # shapes outside the fused kernel run), same operands, timed back to back per layer
+        with torch.no_grad():
+            x = model.entity_embedding
+            rel = model.relation_embedding
+            for li, (layer, table, (agg, out, _)) in enumerate(zip(layers, tables, bufs)):
+                fn = lambda: nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg,
+                                               loop_rel=layer.loop_rel.reshape(-1))
+                fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(K):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                us = a.elapsed_time(b) / K * 1e3
+                ab = agg_kernel_bytes(N, 2 * E, 2 * R, dims[li])
+                kern['aggregate_only_l%d' % (li + 1)] = {'us': us, 'algorithmic_bytes': ab, 'GBps': ab / us / 1e3,
+                                                         'hbm_frac': ab / us / 1e3 / HBM_PEAK_GBS,
+                                                         'note': 'agg_fwd_kernel alone (not part of the timed step)'}
+                rel = nat.matmul(rel, layer.rels_weight)
+                x = out
+    cand = {k: v for k, v in kern.items() if not k.startswith(('relproj', 'layer1', 'layer2', 'aggregate_only'))}
     dom = max(cand, key=lambda k: cand[k]['us'])
     k = kern[dom]
     if dom.startswith('layer_fused'):
