@@ -185,16 +185,24 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
         bufs.append((torch.empty((N, 3 * layer.in_channels), device=model.entity_embedding.device),
                      torch.empty((N, O), device=model.entity_embedding.device), layer.derived_weights()))
 
+    rel_outs = [torch.empty((2 * R, O), device=model.entity_embedding.device) for _ in layers]
+
     def sequence(events):
         x, rel = model.entity_embedding, model.relation_embedding
         i = 0
         for layer, table, (agg, out, (wcat, wpack)) in zip(layers, tables, bufs):
             bn = layer.ent_bn
             events[i].record(); i += 1
-            if fused:
+            if fused:     # one launch: the layer + a few workgroups for the relation projection (model.py:107)
+                rel_next = rel_outs[len(rel_outs) - len(layers) + layers.index(layer)]
                 nat.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table, True, layer.loop_edge.reshape(-1), wpack,
-                                    O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
+                                    O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                                    rels_weight=layer.rels_weight.detach(), rel_out=rel_next)
                 events[i].record(); i += 1
+                events[i].record(); i += 1
+                rel = rel_next
+                x = out
+                continue
             else:
                 nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1))
                 events[i].record(); i += 1
@@ -235,7 +243,8 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
                                             'mfma_f32_frac': fl / td / 1e6 / MFMA_F32_PEAK_TFLOPS}
             kern['layer%d' % (li + 1)] = {'us': ta + td, 'algorithmic_bytes': lb,
                                           'hbm_frac': lb / (ta + td) / 1e3 / HBM_PEAK_GBS}
-        kern['relproj_l%d' % (li + 1)] = {'us': times['relproj_l%d' % (li + 1)]}
+        if not fused:
+            kern['relproj_l%d' % (li + 1)] = {'us': times['relproj_l%d' % (li + 1)]}
     if fused:
         # the HBM-bound part on its own: the aggregation launch of the unfused path (what training's forward and
         # shapes outside the fused kernel run) on the same operands, the layers alternating as in a real step so

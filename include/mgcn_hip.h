@@ -192,7 +192,10 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * then the hub slots [chunks[chunk_begin].begin, chunks[chunk_end - 1].end) of the same nodes — and passes
  * ee_sub_in / ee_sub_out / ee_sub_hub such that the row of (absolute) slot s is s - ee_sub_{region}; with the whole
  * table all three are 0. x_dev is always the whole [N, D] layer input.
- * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [chunk_end - chunk_begin, dim_in]. */
+ * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [chunk_end - chunk_begin, dim_in].
+ * rel_out_dev (optional, [num_rel_rows - 1, dim_out]) = rel_dev @ rels_weight_dev [dim_in, dim_out] (model.py:107, the
+ * relations the next layer / the scorer read) computed by a few extra workgroups of the same launch with the
+ * arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed. */
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
@@ -202,7 +205,7 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
                          float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
                          int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, const int32_t *hubinfo_dev,
                          const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
-                         void *stream);
+                         const float *rels_weight_dev, float *rel_out_dev, void *stream);
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 

@@ -30,7 +30,7 @@ _SIGNATURES = {
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
-                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
+                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
@@ -266,7 +266,7 @@ def pack_weights(w_cat, out=None):
 
 
 def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
-                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0)):
+                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0), rels_weight=None, rel_out=None):
     """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
     `w_packed` = pack_weights(stacked [3D, O] weights). With `node_range` = (n0, n1) only those destinations are
     computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
@@ -294,6 +294,14 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
             raise NativeError('layer_fwd_fused: per-column vectors must have %d elements' % O)
     if tuple(out.shape) != (n1 - n0, O):
         raise NativeError('layer_fwd_fused: out must be (%d, %d)' % (n1 - n0, O))
+    if (rels_weight is None) != (rel_out is None):
+        raise NativeError('layer_fwd_fused: give rels_weight and rel_out together')
+    if rel_out is not None:
+        _same_device(x, rels_weight, rel_out)
+        if tuple(rels_weight.shape) != (D, O) or not rels_weight.is_contiguous() or \
+                tuple(rel_out.shape) != (csr.num_rel_rows - 1, O) or not rel_out.is_contiguous():
+            raise NativeError('layer_fwd_fused: rels_weight must be contiguous (%d, %d) and rel_out (%d, %d)'
+                              % (D, O, csr.num_rel_rows - 1, O))
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
     _check(lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
@@ -304,7 +312,8 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(bn_gamma, torch.float32, 'bn_gamma'), _dev(bn_beta, torch.float32, 'bn_beta'), float(eps),
         _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), int(ee_sub[2]),
         hub_info, hub_chunks, hub_c0, hub_c1,
-        _dev(hub_partial, torch.float32, 'partial', True), _stream(x)), 'mgcn_layer_fwd_fused')
+        _dev(hub_partial, torch.float32, 'partial', True), _dev(rels_weight, torch.float32, 'rels_weight', True),
+        _dev(rel_out, torch.float32, 'rel_out', True), _stream(x)), 'mgcn_layer_fwd_fused')
     return out
 
 

@@ -49,6 +49,9 @@ struct FusedArgs {
   const int2 *hubinfo;    // [2][N] (first chunk, chunk count) or null
   const float *partial;   // [chunks in play][D]; row (first chunk - chunk0) of a hub holds its folded total (pre-pass)
   int32_t chunk0;
+  const float *rw;        // relation projection: rels_weight [D, O] (model.py:107) or null
+  float *rel_out;         // [rel_rows - 1, O] = rel @ rels_weight
+  int32_t rel_blocks;     // the first rel_blocks workgroups compute rel_out and leave
   int32_t ablate;  // timing diagnostics only (MGCN_FUSED_ABLATE): bit 0 skips the gather, bit 1 the MFMA loop
   float bn_eps;
 };
@@ -102,6 +105,47 @@ __device__ __forceinline__ void finalize_tile(const FusedArgs &p, const float *O
   }
 }
 
+// all_rel = rel @ rels_weight (model.py:107; the dropped last row means the loop row is never multiplied). The
+// arithmetic is small_matmul_kernel's, item for item (one output row x 64 columns per four waves; the waves split K
+// in quarters and run sequential fmaf chains; the four partial sums are added in wave order), so the fused layer
+// returns bit-identical relations. Run by the first `rel_blocks` workgroups of the launch, two items at a time.
+__device__ __forceinline__ void relation_projection(const FusedArgs &p, float *lds) {
+  constexpr int UNR = 8;
+  float *part = lds;                                  // [2][4][64]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = wave >> 2, w = wave & 3;
+  const int rows = p.rel_rows - 1, k = p.d, n = p.o;
+  const int ngrp = (n + 63) / 64, items = rows * ngrp;
+  const int kper = (k + 3) / 4, k0 = w * kper, k1 = (k0 + kper < k) ? k0 + kper : k;
+  for (int base = int(blockIdx.x) * 2; base < items; base += p.rel_blocks * 2) {   // block-uniform trip count
+    const int item = base + half;
+    const bool valid = item < items;
+    const int row = valid ? item / ngrp : 0, col = (valid ? item - row * ngrp : 0) * 64 + lane;
+    const bool ok = valid && col < n;
+    const float *ap = p.rel + int64_t(row) * k;
+    const float *bp = p.rw + (ok ? col : 0);
+    float acc = 0.f;
+    int kk = k0;
+    for (; kk + UNR <= k1; kk += UNR) {
+      float av[UNR], bv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        av[u] = ap[kk + u];
+        bv[u] = bp[int64_t(kk + u) * n];
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc = fmaf(av[u], bv[u], acc);
+    }
+    for (; kk < k1; ++kk) acc = fmaf(ap[kk], bp[int64_t(kk) * n], acc);
+    part[(half * 4 + w) * 64 + lane] = acc;
+    __syncthreads();
+    if (w == 0 && ok) {
+      const float *q = part + half * 256 + lane;
+      p.rel_out[int64_t(row) * n + col] = ((q[0] + q[64]) + q[128]) + q[192];
+    }
+    __syncthreads();
+  }
+}
+
 // PERSISTENT: a block walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and the gather -> multiply pipeline runs
 // straight across tile boundaries: stage s = 3*tile + mode; while the MFMA waves multiply stage s the gather waves
 // fetch stage s + 1 (the next tile's in-half when s is a self-loop stage). One workgroup barrier per stage. A
@@ -117,12 +161,17 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
   float *As = lds;                     // [2][BM][lda]
   float *Os = lds + 2 * BM * lda;      // [BM][LDO] epilogue staging (2*BM*lda*4 bytes is a multiple of 16)
 
+  if (int(blockIdx.x) < p.rel_blocks) {   // workgroup-uniform: these workgroups only project the relations
+    relation_projection(p, lds);
+    return;
+  }
+  const int bid = int(blockIdx.x) - p.rel_blocks, nblk = int(gridDim.x) - p.rel_blocks;   // tile workgroups
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool mfma_role = wave < 4;
   const int nkb = (p.d + KS - 1) / KS;
   const int ntiles = (p.node1 - p.node0 + BM - 1) / BM;
-  const int my_tiles = (ntiles - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);  // >= 1 (grid <= ntiles)
+  const int my_tiles = (ntiles - bid + nblk - 1) / nblk;  // >= 1 (tile workgroups <= ntiles)
 
   // The two roles are two separate programs (disjoint live ranges -> each fits the register budget); both
   // execute exactly 3 * my_tiles + 1 workgroup barriers.
@@ -138,7 +187,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     const float *xb = p.x + coff, *relb = p.rel + coff, *eeb = p.ee + coff;
     const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
     auto finalize = [&](int tile_it) {
-      if (!(p.ablate & 4)) finalize_tile(p, Os, LDO, (int(blockIdx.x) + tile_it * int(gridDim.x)) * BM, gtid);
+      if (!(p.ablate & 4)) finalize_tile(p, Os, LDO, (bid + tile_it * nblk) * BM, gtid);
     };
     // A stage's memory chain is row pointers -> slot records -> rows. The first two links are fetched ONE STAGE
     // AHEAD: lane i of a group holds the row pointer of destination g_lo + i and the record of slot beg + i (the
@@ -146,7 +195,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     // whole group through ds_bpermute. Runs longer than the group (hub-free runs are <= 64 slots per destination)
     // reload the record chunk on demand.
     auto rp_of = [&](int it_, int mode_) {
-      int node = p.node0 + (int(blockIdx.x) + it_ * int(gridDim.x)) * BM + g_lo + (lig <= rpg ? lig : rpg);
+      int node = p.node0 + (bid + it_ * nblk) * BM + g_lo + (lig <= rpg ? lig : rpg);
       node = node < p.node1 ? node : p.node1;
       return p.rowptr[int64_t(mode_) * (p.n + 1) + node];   // absolute slot position
     };
@@ -159,7 +208,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     int4 currec = rec_chunk(__shfl(currp, glane0), __shfl(currp, glane0 + rpg));
     int stage = 0;
     for (int it = 0; it < my_tiles; ++it) {
-      const int r0 = p.node0 + (int(blockIdx.x) + it * int(gridDim.x)) * BM;
+      const int r0 = p.node0 + (bid + it * nblk) * BM;
       for (int mode = 0; mode < 3; ++mode, ++stage) {
         float *at = As + (stage & 1) * BM * lda;
         if (mode == 2 && it > 0) finalize(it - 1);   // Os holds tile it-1 since the barrier two stages back
@@ -274,7 +323,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 4) void layer_fused_kernel(FusedArgs
     constexpr int Q4 = NT / 4, R4 = NT % 4;
     static_assert(R4 != 3, "column tile counts with NT % 4 == 3 are not instantiated");
     constexpr int QF = Q4 > 0 ? Q4 : 1;            // array extent for the full tiles (Q4 may be 0)
-    const int wsel = wave ^ ((int(blockIdx.x >> 8) & 1) << 1);
+    const int wsel = wave ^ (((bid >> 8) & 1) << 1);
     const int ct0 = wsel * Q4;
     const bool has_half = R4 == 2 || (R4 == 1 && wsel < 2);
     const int hct = 4 * Q4 + (R4 == 2 ? (wsel >> 1) : 0);   // the shared column tile of this wave's single unit
@@ -408,7 +457,8 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                     float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
                                     int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub,
                                     const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t chunk_begin,
-                                    int64_t chunk_end, float *partial_dev, void *stream) {
+                                    int64_t chunk_end, float *partial_dev, const float *rels_weight_dev,
+                                    float *rel_out_dev, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
                "layer_fwd_fused: bad sizes");
   MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "layer_fwd_fused: bad node range");
@@ -429,9 +479,11 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   MGCN_REQUIRE(chunk_begin >= 0 && num_chunks >= 0 && chunk_end < (int64_t(1) << 31) &&
                    (num_chunks == 0 || (hubinfo_dev && chunks_dev && partial_dev && mgcn::aligned16(partial_dev))),
                "layer_fwd_fused: hub chunks need hubinfo / chunks / a 16-byte aligned partial buffer");
-  if (node_end == node_begin) return MGCN_OK;
+  const bool want_rel = rel_out_dev != nullptr && num_rel_rows > 1;
+  MGCN_REQUIRE(!want_rel || (rels_weight_dev && rel_dev), "layer_fwd_fused: the relation projection needs rels_weight and rel");
+  if (node_end == node_begin && !want_rel) return MGCN_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (num_chunks > 0) {
+  if (num_chunks > 0 && node_end > node_begin) {
     if (int rc = mgcn::launch_hub_partials(num_nodes, dim_in, num_rel_rows, rec_dev, x_dev, ldx, rel_dev, loop_rel_dev,
                                            ee_dev, ee_in_slot_order, ee_sub_hub, chunks_dev, chunk_begin, chunk_end,
                                            partial_dev, stream))
@@ -459,7 +511,16 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   const size_t lds_bytes = (size_t(2) * BM * lda + size_t(BM) * ldo_s) * 4;
   int grid_i = 2 * 256;   // persistent: two 8-wave blocks per CU (128 VGPRs, <= 80 KiB LDS each)
   if (const char *g = getenv("MGCN_FUSED_GRID")) grid_i = atoi(g);
-  const unsigned grid = unsigned(grid_i < ntiles ? grid_i : ntiles);
+  const int main_grid = grid_i < ntiles ? grid_i : ntiles;
+  if (want_rel) {   // a few extra workgroups project the relations (model.py:107): one or two items each when the tile
+    // workgroups fill the chip anyway, else as many as fit beside them
+    const int items = (num_rel_rows - 1) * ((dim_out + 63) / 64);
+    const int cap = main_grid < 2 * 256 ? 2 * 256 - main_grid : 48;
+    int rb = (items + 1) / 2;
+    rb = rb < 1 ? 1 : (rb > cap ? cap : rb);
+    p.rw = rels_weight_dev; p.rel_out = rel_out_dev; p.rel_blocks = rb;
+  }
+  const unsigned grid = unsigned(main_grid + p.rel_blocks);
   switch (nt) {
     case 2: hipLaunchKernelGGL((layer_fused_kernel<2>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;
     case 4: hipLaunchKernelGGL((layer_fused_kernel<4>), dim3(grid), dim3(FUSED_THREADS), lds_bytes, st, p); break;

@@ -180,9 +180,13 @@ class MGCNConv(nn.Module):
             bn = self.ent_bn
             wcat, wpack = (self._wcat, self._wpack) if _capturing(x) else self.derived_weights()
             if wpack is not None and ee_in_slot_order:   # (a table in edge-id order takes the two-launch path)
+                # one launch: the layer, and a few extra workgroups for (rels @ W)[:-1] (model.py:107)
+                all_rel = torch.empty((rels_embs.size(0), self.out_channels), dtype=torch.float32, device=x.device)
                 _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
                                         ee_in_slot_order, self.loop_edge.reshape(-1), wpack, self.out_channels, self.bias,
-                                        bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
+                                        bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent,
+                                        rels_weight=self.rels_weight.detach().contiguous(), rel_out=all_rel)
+                return all_ent, all_rel
             else:
                 self._two_launch_layer(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order, all_ent)
             # (rels @ W)[:-1] drops the self-loop row, so the projection needs no concatenation (model.py:107)
