@@ -28,7 +28,7 @@ loop_rel, loop_edge = torch.randn(D, device=dev), torch.randn(D, device=dev)
 # this rank's destinations need their own slots of the per-edge table only; the kernel is handed the FULL slot index
 # space, so allocate just the rows it touches by giving it a table view that starts at this range's first in-half slot
 ee_full_rows = 2 * E
-(i0, i1), (o0, o1) = csr._shard_bounds(n0, n1)
+(i0, i1), (o0, o1), _hub = csr._shard_bounds(n0, n1)
 agg = torch.empty((n1 - n0, 3 * D), device=dev)
 out = {'N': N, 'E': E, 'R': R, 'D': D, 'world': W, 'rank': RANK, 'dest_range': [n0, n1], 'slots': slots,
        'csr_build_s': round(t_build, 2)}
