@@ -302,6 +302,10 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
                 tuple(rel_out.shape) != (csr.num_rel_rows - 1, O) or not rel_out.is_contiguous():
             raise NativeError('layer_fwd_fused: rels_weight must be contiguous (%d, %d) and rel_out (%d, %d)'
                               % (D, O, csr.num_rel_rows - 1, O))
+    if n1 == n0 and rel_out is None:
+        return out                                   # an empty destination range: nothing to launch
+    if ee is not None and ee.numel() == 0:           # a range whose destinations have no slots: the kernel still wants
+        ee = x.new_zeros((1, D))                     # a valid (never read) table pointer
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
     _check(lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),

@@ -465,7 +465,7 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 64 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "layer_fwd_fused: sizes exceed int32");
   MGCN_REQUIRE(rowptr_dev && x_dev && loop_rel_dev && loop_edge_dev && wp_dev && bn_mean_dev && bn_var_dev &&
-                   bn_gamma_dev && bn_beta_dev && out_dev && (rel_dev || num_rel_rows == 1) &&
+                   bn_gamma_dev && bn_beta_dev && (out_dev || node_end == node_begin) && (rel_dev || num_rel_rows == 1) &&
                    (num_edges_half == 0 || rec_dev), "layer_fwd_fused: null pointer");
   MGCN_REQUIRE(ldx >= dim_in && ldo >= dim_out, "layer_fwd_fused: ldx/ldo too small");
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&

@@ -471,6 +471,8 @@ def test_destination_ranges_with_table_shards(pkg, case, hubs):
     parts = [run(b[r], b[r + 1], csr.edge_table_shard(table, b[r], b[r + 1]), csr.shard_ee_sub(b[r], b[r + 1]))
              for r in range(3)]
     assert torch.equal(torch.cat(parts, dim=0), full)
+    empty = run(b[1], b[1], csr.edge_table_shard(table, b[1], b[1]), csr.shard_ee_sub(b[1], b[1]))
+    assert tuple(empty.shape) == (0, O)                        # an empty range (and its empty shard) is a no-op
     with pytest.raises(nat.NativeError):                       # a shard that does not belong to the range is refused
         run(b[0], b[1], csr.edge_table_shard(table, b[1], b[2]), csr.shard_ee_sub(b[1], b[2]))
 
