@@ -474,6 +474,162 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
   }
 }
 
+// RANK with the query block RESIDENT in LDS (main.py:122-126 for up to 128 queries per strip): the tile kernel
+// re-stages the [K, 128] query slabs for every 32-entity row tile (131 MB of L2 -> LDS traffic and a transposing
+// ds_write pass per k-block for one WN18RR batch); here a 512-thread block transposes its strip of x into LDS once
+// and its two half-blocks (four waves each, the tile kernel's wave layout) walk the entity row tiles, streaming only
+// the entity rows (one dwordx4 per lane and k-block, the next tile's rows in flight under the current tile's MFMAs).
+// Same k grouping per MFMA step, same accumulation order and the same sigmoid as tile_kernel, so scores — and
+// therefore counts — are bit-identical to the other scoring kernels.
+constexpr int RANK_NT = 8, RANK_MAX_KB = 16;   // 128 queries per strip, K <= 256
+__global__ __launch_bounds__(512, 2) void rank_resident_kernel(TileArgs p) {
+  constexpr int NT = RANK_NT, BNC = NT * 16, LDB = BNC + 4, NTW = NT / 2;
+  extern __shared__ __attribute__((aligned(16))) float Bs[];   // [nkb * 16][LDB], then 3 * BNC counters
+  const int nkb = (p.k + KS - 1) / KS, kpad = nkb * KS;
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(Bs + kpad * LDB);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int half = wave >> 2, w4 = wave & 3, rt = w4 & 1, ch = w4 >> 1, ct0 = ch * NTW;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int c0 = int(blockIdx.y) * BNC;
+  // x strip -> Bs[k][query] (k rows past K are zero; queries past the batch repeat the last one, never counted)
+  // lane -> (16 queries) x (4 k-quads): 64-byte global pieces per query row, two-way LDS bank conflicts at most
+  const int kq4 = kpad / 4, kq4p = (kq4 + 3) / 4 * 4;
+  for (int idx = tid; idx < (BNC / 16) * (kq4p / 4) * 64; idx += 512) {
+    const int grp = idx >> 6, l = idx & 63;
+    const int c = (grp % (BNC / 16)) * 16 + (l & 15), kk = ((grp / (BNC / 16)) * 4 + (l >> 4)) * 4;
+    if (kk >= kpad) continue;
+    int col = c0 + c;
+    col = col < p.ncols ? col : p.ncols - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kk < p.k) v = *reinterpret_cast<const float4 *>(p.b + int64_t(col) * p.ldb + kk);
+    Bs[(kk + 0) * LDB + c] = v.x;
+    Bs[(kk + 1) * LDB + c] = v.y;
+    Bs[(kk + 2) * LDB + c] = v.z;
+    Bs[(kk + 3) * LDB + c] = v.w;
+  }
+  for (int i = tid; i < BNC * 3; i += 512) cnt[i] = 0;
+  __syncthreads();
+
+  unsigned int my_gt[NTW], my_tl[NTW], my_ti[NTW];
+  float tgt[NTW];
+  int64_t ob[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    my_gt[t] = my_tl[t] = my_ti[t] = 0;
+    int col = c0 + (ct0 + t) * 16 + fr;
+    col = col < p.ncols ? col : p.ncols - 1;
+    tgt[t] = p.target[col];
+    ob[t] = p.obj[col] - p.row0;
+  }
+  auto aload = [&](float4 (&a)[RANK_MAX_KB], int tm) {
+    int64_t arow = int64_t(tm) * BM + rt * 16 + fr;
+    arow = arow < p.m ? arow : p.m - 1;                 // rows past M are computed from a valid row and never counted
+    const float *ap = p.a + arow * p.lda + 4 * fq;
+#pragma unroll
+    for (int kb = 0; kb < RANK_MAX_KB; ++kb) {
+      a[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb < nkb && kb * KS + 4 * fq < p.k) a[kb] = *reinterpret_cast<const float4 *>(ap + kb * KS);
+    }
+  };
+  // the tile's filter words (its 32 rows are one 32-bit word per query) and entity biases travel with the A rows
+  auto eload = [&](uint32_t (&mw)[NTW], float (&bv)[4], int tm) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      int col = c0 + (ct0 + t) * 16 + fr;
+      col = col < p.ncols ? col : p.ncols - 1;
+      mw[t] = p.mask ? p.mask[int64_t(col) * p.ldl + tm] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t row = int64_t(tm) * BM + rt * 16 + fq * 4 + j;
+      row = row < p.m ? row : p.m - 1;
+      bv[j] = p.bias[row];
+    }
+  };
+  float4 a_cur[RANK_MAX_KB], a_nxt[RANK_MAX_KB];
+  uint32_t m_cur[NTW], m_nxt[NTW];
+  float b_cur[4], b_nxt[4];
+  const int step = int(gridDim.x) * 2;
+  int tm = int(blockIdx.x) * 2 + half;
+  if (tm < p.tiles_m) {
+    aload(a_cur, tm);
+    eload(m_cur, b_cur, tm);
+  }
+  for (; tm < p.tiles_m; tm += step) {
+    if (tm + step < p.tiles_m) {
+      aload(a_nxt, tm + step);
+      eload(m_nxt, b_nxt, tm + step);
+    }
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < RANK_MAX_KB; ++kb) {
+      if (kb < nkb) {
+        const float *bs = Bs + (kb * KS + 4 * fq) * LDB + ct0 * 16 + fr;
+        const float av[4] = {a_cur[kb].x, a_cur[kb].y, a_cur[kb].z, a_cur[kb].w};
+        float bf[2][NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) bf[0][t] = bs[t * 16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i + 1 < 4) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) bf[(i + 1) & 1][t] = bs[(i + 1) * LDB + t * 16];
+          }
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bf[i & 1][t], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    const int64_t r0 = int64_t(tm) * BM;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int col = c0 + (ct0 + t) * 16 + fr;
+      if (col >= p.ncols) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = r0 + rt * 16 + fq * 4 + j;
+        if (row >= p.m || row == ob[t]) continue;                          // the target itself (main.py:125)
+        if (p.mask) {
+          if ((m_cur[t] >> (rt * 16 + fq * 4 + j)) & 1u) continue;          // BM = 32 rows = one filter word
+        } else {
+          const float lab = p.label[int64_t(col) * p.ldl + row];
+          if ((static_cast<int>(lab) & 0xff) != 0) continue;                // label.byte() filter (main.py:124)
+        }
+        const float sc = sigmoidf_(acc[t][j] + b_cur[j]);
+        my_gt[t] += sc > tgt[t];
+        const bool eq = sc == tgt[t];
+        my_ti[t] += eq;
+        my_tl[t] += eq && (row < ob[t]);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < RANK_MAX_KB; ++kb) a_cur[kb] = a_nxt[kb];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) m_cur[t] = m_nxt[t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
+  }
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    unsigned int g = my_gt[t], l = my_tl[t], e = my_ti[t];
+    g += __shfl_xor(g, 16); l += __shfl_xor(l, 16); e += __shfl_xor(e, 16);
+    g += __shfl_xor(g, 32); l += __shfl_xor(l, 32); e += __shfl_xor(e, 32);
+    if (fq == 0) {
+      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 0], g);
+      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 1], l);
+      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 2], e);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < BNC * 3; i += 512) {
+    const int col = c0 + i / 3;
+    if (col < p.ncols && cnt[i]) atomicAdd(&p.counts[int64_t(col) * 3 + i % 3], (unsigned long long)cnt[i]);
+  }
+}
+
 // all_rel = rels_embs @ rels_weight (model.py:107 without the dropped last row): [T, K] x [K, O], T tiny, so
 // the kernel is pure latency. Block = (one output row, 64 columns); its 4 waves split K and keep UNR
 // independent loads in flight per lane; partial sums meet in LDS and are added in wave order.
@@ -744,6 +900,24 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
   p.ldl = label_dev ? ldl : ldm;
   p.counts = reinterpret_cast<unsigned long long *>(counts_dev); p.row0 = ent_row0;
   p.m = n_local; p.k = dim; p.ncols = batch;
+  set_vec_flags(&p);
+  p.tiles_m = int32_t((p.m + BM - 1) / BM);
+  if (p.a_vec && p.b_vec && dim % 4 == 0 && dim <= RANK_MAX_KB * KS && !getenv("MGCN_RANK_TILE")) {
+    // aligned shapes with K <= 256: the query strip stays in LDS (rank_resident_kernel)
+    const int nkb = (dim + KS - 1) / KS;
+    const size_t lds = (size_t(nkb) * KS * (RANK_NT * 16 + 4) + size_t(RANK_NT) * 16 * 3) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
+    const int pairs = (p.tiles_m + 1) / 2;
+    const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
+    hipLaunchKernelGGL(rank_resident_kernel, dim3(gx, gy), dim3(512), lds, static_cast<hipStream_t>(stream), p);
+    MGCN_CHECK_LAUNCH("rank_resident_kernel");
+    return MGCN_OK;
+  }
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
 }
 
