@@ -294,7 +294,7 @@ struct BwdArgs {
   int32_t n, e, d, rel_rows, nchunks_type;
 };
 
-constexpr int kTypeChunk = 64;  // slots per partial sum of the by-type reduction
+constexpr int kTypeChunk = 16;  // slots per partial sum of the by-type reduction (short chunks = many lane groups in flight)
 
 // gee[slot] = (g[dst, half] * norm) * x[src] * rel[type]; one group per slot, fully streamed store.
 template <int VEC, int CPL>
@@ -494,28 +494,64 @@ __global__ __launch_bounds__(256) void agg_bwd_grel_partial_kernel(BwdArgs p, in
   }
 }
 
-// Stage 2: grel[t] = partial[nchunks + t] + partial[c] for every chunk boundary strictly inside t's range.
+// Stage 2: grel[t] = partial[nchunks + t] + partial[c] for every chunk boundary strictly inside t's range. One
+// workgroup per relation row: lane group j adds the chunk rows j, j + J, j + 2J, ... of the range in that order (four
+// loads in flight), then group 0 adds the head row and the J group sums in group order — a fixed summation tree.
 template <int VEC, int CPL>
 __global__ __launch_bounds__(256) void agg_bwd_grel_final_kernel(BwdArgs p, int gs_log2) {
   using V = Vec<VEC>;
   using T = typename V::type;
-  const int gs = 1 << gs_log2;
-  const int lig = threadIdx.x & (gs - 1);
-  const int64_t t = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
-  if (t >= p.rel_rows) return;
+  extern __shared__ float red[];  // [J][D]
+  constexpr int U = 4;
+  const int gs = 1 << gs_log2, groups = 256 >> gs_log2;
+  const int grp = threadIdx.x >> gs_log2, lig = threadIdx.x & (gs - 1);
+  const int64_t t = blockIdx.x;
   const int nchunk = p.d / VEC;
   const int64_t lo = p.typeptr[t], hi = p.typeptr[t + 1];
+  const int64_t cb0 = lo / kTypeChunk + 1;                                   // first chunk boundary inside the range
+  const int64_t ncb = hi > lo ? (hi - 1) / kTypeChunk - cb0 + 1 : 0;         // chunk rows to add (may be <= 0)
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  for (int64_t k = grp; k < ncb; k += int64_t(groups) * U) {
+    T v[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t kk = k + int64_t(u) * groups;
+      if (kk >= ncb) continue;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) v[u][c] = V::load(p.ws + (cb0 + kk) * p.d + ch * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + int64_t(u) * groups >= ncb) continue;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = lig + c * gs;
+        if (ch < nchunk) acc[c] = V::add(acc[c], v[u][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) V::store(red + grp * p.d + ch * VEC, acc[c]);
+  }
+  __syncthreads();
+  if (grp != 0) return;
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lig + c * gs;
     if (ch >= nchunk) continue;
-    T acc = V::zero();
+    T tot = V::zero();
     if (hi > lo) {
-      acc = V::load(p.ws + (int64_t(p.nchunks_type) + t) * p.d + ch * VEC);
-      for (int64_t cb = lo / kTypeChunk + 1; cb * kTypeChunk < hi; ++cb)
-        acc = V::add(acc, V::load(p.ws + cb * p.d + ch * VEC));
+      tot = V::load(p.ws + (int64_t(p.nchunks_type) + t) * p.d + ch * VEC);
+      for (int j = 0; j < groups; ++j) tot = V::add(tot, V::load(red + j * p.d + ch * VEC));
     }
-    V::store(p.grel + t * p.d + ch * VEC, acc);
+    V::store(p.grel + t * p.d + ch * VEC, tot);
   }
 }
 
@@ -795,7 +831,27 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
       MGCN_LAUNCH_GEOM(agg_bwd_grel_partial_kernel, p, p.nchunks_type, g, stream);
       MGCN_CHECK_LAUNCH("agg_bwd_grel_partial_kernel");
     }
-    MGCN_LAUNCH_GEOM(agg_bwd_grel_final_kernel, p, num_rel_rows, g, stream);
+    {
+      const size_t lds = size_t(256 >> g.gs_log2) * size_t(dim) * sizeof(float);
+      hipStream_t st = static_cast<hipStream_t>(stream);
+#define MGCN_GRELF_CASE(V_, C_) hipLaunchKernelGGL((agg_bwd_grel_final_kernel<V_, C_>), dim3(unsigned(num_rel_rows)), dim3(256), lds, st, p, g.gs_log2)
+      if (g.vec == 4) {
+        switch (g.cpl) {
+          case 1: MGCN_GRELF_CASE(4, 1); break;
+          case 2: MGCN_GRELF_CASE(4, 2); break;
+          case 4: MGCN_GRELF_CASE(4, 4); break;
+          default: MGCN_GRELF_CASE(4, 8); break;
+        }
+      } else {
+        switch (g.cpl) {
+          case 1: MGCN_GRELF_CASE(1, 1); break;
+          case 2: MGCN_GRELF_CASE(1, 2); break;
+          case 4: MGCN_GRELF_CASE(1, 4); break;
+          default: MGCN_GRELF_CASE(1, 8); break;
+        }
+      }
+#undef MGCN_GRELF_CASE
+    }
     MGCN_CHECK_LAUNCH("agg_bwd_grel_final_kernel");
   }
   return MGCN_OK;
