@@ -31,14 +31,19 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
-def synth_graph(shape, seed=0):
-    """Uniform random triples of the given shape (numpy default_rng, duplicates kept), plus the
-    bi-directional edge list exactly as the feeder expects it (data_loader.py:143-149)."""
+def synth_graph(shape, seed=0, zipf=0.0):
+    """Random triples of the given shape (numpy default_rng, duplicates kept), plus the bi-directional edge list exactly
+    as the feeder expects it (data_loader.py:143-149). Uniform endpoints by default; zipf > 0 draws the tails from a
+    Zipf-like law over a random permutation of the entities (the power-law profile that exercises hubs)."""
     rng = np.random.default_rng(seed)
     N, R, E = shape['N'], shape['R'], shape['E']
     s = rng.integers(0, N, size=E)
     r = rng.integers(0, R, size=E)
-    o = rng.integers(0, N, size=E)
+    if zipf > 0:
+        w = 1.0 / np.arange(1, N + 1) ** zipf
+        o = rng.permutation(N)[rng.choice(N, size=E, p=w / w.sum())]
+    else:
+        o = rng.integers(0, N, size=E)
     edge_index = np.stack((np.concatenate((s, o)), np.concatenate((o, s))))
     edge_attr = np.stack((np.concatenate((r, r + R)), np.arange(2 * E, dtype=np.int64)))
     return torch.from_numpy(edge_index), torch.from_numpy(edge_attr)
@@ -62,6 +67,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--shape', default='wn18rr', choices=sorted(SHAPES))
     ap.add_argument('--layers', type=int, default=2)
+    ap.add_argument('--zipf', type=float, default=0.0, help='tail endpoints ~ Zipf(a) instead of uniform (hub-heavy profile)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
     args = ap.parse_args()
@@ -96,7 +102,7 @@ def main():
                                    gcn_layers=args.layers, cache_encoder=False, device=dev)
 
     # every rank works on its own graph of the same shape (seed = rank): per-GPU work fixed -> weak scaling
-    edge_index, edge_attr = synth_graph(shape, seed=rank)
+    edge_index, edge_attr = synth_graph(shape, seed=rank, zipf=args.zipf)
     graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
     graph.entity = torch.arange(N)
     graph.num_nodes = N
@@ -139,8 +145,9 @@ def main():
         'metric': 'aggregated_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s-shape synthetic graph (N=%d, R=%d, E=%d), %d-layer M-GCN encoder %s, full-graph '
-                               'forward, eval mode' % (args.shape, N, R, E, args.layers,
+        'config': {'workload': '%s-shape synthetic graph (N=%d, R=%d, E=%d%s), %d-layer M-GCN encoder %s, full-graph '
+                               'forward, eval mode' % (args.shape, N, R, E, ', Zipf(%.2f) tails' % args.zipf if args.zipf else '',
+                                                       args.layers,
                                                        '->'.join(map(str, [D] + [O] * args.layers))),
                    'edges_per_step_per_gpu': edges_per_step,
                    'parallelism': 'one graph of this shape per GPU x%d, no data-path collective in the encoder step; '
@@ -151,7 +158,7 @@ def main():
         result.update(kernel_breakdown(pkg, model, graph, args, N, R, E, D, O))
     if not args.no_eval:                                    # every rank takes part (collectives when W > 1)
         if rank != 0:                                       # the sharded pass needs ONE graph on all ranks: rank 0's
-            edge_index, edge_attr = synth_graph(shape, seed=0)
+            edge_index, edge_attr = synth_graph(shape, seed=0, zipf=args.zipf)
             graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
             graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
             graph.to(dev)                                   # (the per-edge tables are re-laid out for it on first use)
