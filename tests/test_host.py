@@ -435,3 +435,33 @@ def test_dropin_module_names(pkg):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_abi_argument_validation_without_a_gpu(pkg):
+    """Every device entry point validates its arguments before any HIP call: bad sizes / null pointers come back as
+    MGCN_EINVAL (1) with a message, on a machine without a GPU too."""
+    lib = pkg._native.lib()
+    N = None
+    cases = [
+        ('mgcn_aggregate_fwd', (-1, 0, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 0, N, N, 0, 0, N, N), 'bad sizes'),
+        ('mgcn_aggregate_fwd', (4, 2, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 4, N, N, 0, 0, N, N), 'null pointer'),
+        ('mgcn_aggregate_bwd', (4, 2, 0, 3, N, N, N, N, N, N, 0, N, N, N, 4, N, N, N, 8, N, N, N, N, 0, N), 'bad sizes'),
+        ('mgcn_dense_bn_tanh_fwd', (4, 4, 4, N, 12, N, N, N, N, N, N, 1e-5, N, 4, N), 'null pointer'),
+        ('mgcn_layer_fwd_fused', (4, 2, 4, 4, 3, N, N, N, 4, N, N, N, 1, N, N, N, N, N, N, N, 1e-5, N, 4, 2, 1, 0, 0, 0, N, N, 0,
+                                  0, N, N, N, N), 'bad node range'),
+        ('mgcn_score_fwd', (4, 8, 4, N, 4, N, 4, N, N, 8, N), 'null pointer'),
+        ('mgcn_score_rank', (4, 8, 0, 4, N, 4, N, 4, N, N, N, N, 0, N, 0, N, N), 'null pointer'),
+        ('mgcn_filter_mask', (4, N, 0, N, N, N, 0, 8, N, 1, N), 'null pointer'),
+        ('mgcn_label_rows', (4, N, 0, N, N, N, 0, 8, 1.0, 0.0, N, 4, N), 'leading|sizes|null'),
+        ('mgcn_score_bce_fwd', (4, 8, 4, N, 4, N, 4, N, N, 1, 1.0, 0.0, 0.1, N, 4, N, N), 'null pointer'),
+        ('mgcn_matmul_f32', (4, 4, 4, N, 4, N, 4, N, 4, N), 'null pointer'),
+        ('mgcn_pack_weights', (4, 4, N, N, 0, N), 'bad arguments'),
+    ]
+    for name, args, pattern in cases:
+        rc = getattr(lib, name)(*args)
+        msg = lib.mgcn_last_error().decode()
+        assert rc == 1, (name, rc, msg)
+        assert re.search(pattern, msg), (name, msg)
+    assert lib.mgcn_packed_weights_bytes(100, 200) == 3 * 7 * 13 * 64 * 16
+    assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
+    assert lib.mgcn_score_bce_partials(128, 40943) == 1280
