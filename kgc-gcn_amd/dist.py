@@ -101,9 +101,15 @@ def encode_sharded(model, graph, group=None):
     x, rel = model.entity_embedding.detach(), model.relation_embedding.detach()
     tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
     ee_sub = csr.shard_ee_sub(n0, n1)
-    for layer, table in zip(layers, tables):
+    shards = model.__dict__.setdefault('_ee_shard_cache', {})   # the rank's table shards, re-sliced only when a table changes
+    for li, (layer, table) in enumerate(zip(layers, tables)):
         _, wpack = layer.derived_weights()
-        shard = csr.edge_table_shard(table.detach(), n0, n1)   # a deployment at scale keeps ONLY this on the rank
+        key = (li, n0, n1, id(csr))
+        hit = shards.get(key)
+        if hit is None or hit[0] != table._version or hit[1].device != table.device:
+            hit = (table._version, csr.edge_table_shard(table.detach(), n0, n1))   # a deployment at scale keeps ONLY this
+            shards[key] = hit
+        shard = hit[1]
         local = torch.zeros((chunk, layer.out_channels), dtype=torch.float32, device=x.device)
         bn = layer.ent_bn
         _native.layer_fwd_fused(csr, x.contiguous(), rel.contiguous(), layer.loop_rel.reshape(-1), shard, True,
