@@ -906,17 +906,18 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
     // aligned shapes with K <= 256: the query strip stays in LDS (rank_resident_kernel)
     const int nkb = (dim + KS - 1) / KS;
     const size_t lds = (size_t(nkb) * KS * (RANK_NT * 16 + 4) + size_t(RANK_NT) * 16 * 3) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    // more than 64 KB of dynamic LDS: opt in (idempotent, so no state is kept; a failure falls through to the tile kernel)
+    const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!lds_ok) (void)hipGetLastError();
+    if (lds_ok) {
     const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
     const int pairs = (p.tiles_m + 1) / 2;
     const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
     hipLaunchKernelGGL(rank_resident_kernel, dim3(gx, gy), dim3(512), lds, static_cast<hipStream_t>(stream), p);
     MGCN_CHECK_LAUNCH("rank_resident_kernel");
     return MGCN_OK;
+    }
   }
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
 }
