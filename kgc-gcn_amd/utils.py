@@ -17,49 +17,60 @@ def get_param(shape):
 
 
 class Params(object):
-    """Attribute bag backed by a json file."""
+    """Hyper-parameters as attributes, read from / written to a json file (utils.py:10-42)."""
 
     def __init__(self, json_path):
         self.update(json_path)
 
     def update(self, json_path):
-        with open(json_path) as f:
-            self.__dict__.update(json.load(f))
+        with open(json_path) as handle:
+            vars(self).update(json.load(handle))
 
     def save(self, json_path):
-        with open(json_path, 'w') as f:
-            json.dump(self.__dict__, f, indent=4)
+        save_json(vars(self), json_path)
 
     @property
     def dict(self):
-        return self.__dict__
+        return vars(self)
 
 
 class RunningAverage(object):
+    """Mean of the values fed to update() (utils.py:45-66)."""
+
     def __init__(self):
-        self.total, self.steps = 0.0, 0
+        self._sum = 0.0
+        self._count = 0
 
     def update(self, val):
-        self.total += val
-        self.steps += 1
+        self._sum, self._count = self._sum + val, self._count + 1
 
     def __call__(self):
-        return self.total / float(self.steps)
+        return self._sum / float(self._count)
+
+    @property
+    def steps(self):
+        return self._count
+
+    @property
+    def total(self):
+        return self._sum
 
 
 def save_json(obj, json_file):
-    with open(json_file, 'w') as f:
-        json.dump(obj, f, indent=4)
+    with open(json_file, 'w') as handle:
+        json.dump(obj, handle, indent=4)
 
 
 def set_logger(log_path):
-    logger = logging.getLogger()
-    logger.setLevel(logging.INFO)
-    if not logger.handlers:
-        fmt = logging.Formatter('%(asctime)s [%(levelname)s] %(message)s')
-        for h in (logging.FileHandler(log_path), logging.StreamHandler()):
-            h.setFormatter(fmt)
-            logger.addHandler(h)
+    """Root logger at INFO with one file and one console handler, installed once (utils.py:69-95)."""
+    root = logging.getLogger()
+    root.setLevel(logging.INFO)
+    if root.handlers:
+        return
+    layout = logging.Formatter('%(asctime)s [%(levelname)s] %(message)s')
+    for handler in (logging.FileHandler(log_path), logging.StreamHandler()):
+        handler.setFormatter(layout)
+        root.addHandler(handler)
 
 
 def save_checkpoint(state, is_best, checkpoint_dir):
