@@ -133,10 +133,10 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
 
     Rank r owns the contiguous query range [c_r, c_{r+1}) (padded to a common length so every rank runs the same
     collectives). The queries go to the device once, the ConvE trunk runs over them in chunks of `trunk_chunk`, and the
-    score + filter + count exchange runs per block of `batch_size` queries (None = all of a rank's queries in one
-    block: three launches and two collectives per rank in total). Ranks are accumulated on the device and reduced to
-    the metrics once at the end; the result does not depend on `batch_size`. `shard_encoder=True` also partitions the
-    encoder by destination (encode_sharded)."""
+    exchange happens ONCE for the whole evaluation: one all-gather of the query embeddings / keys / objects, one
+    all-reduce of the target scores, one all-reduce of the integer counts. `batch_size` only sets how many queries one
+    score + filter + count launch takes (None = all of them); the result does not depend on it. `shard_encoder=True`
+    also partitions the encoder by destination (encode_sharded)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model.eval()
@@ -158,13 +158,33 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
                                      all_rel.index_select(0, rel[i:i + trunk_chunk]))
                    for i in range(0, per, trunk_chunk)], dim=0) if per > 0 else all_ent.new_zeros((0, all_ent.size(1)))
     keys = filt.query_keys(sub, rel)
-    ranks = torch.zeros(per, dtype=torch.float64, device=dev)
-    step = per if not batch_size else int(batch_size)
-    for i in range(0, per, max(step, 1)):
-        counts, _ = sharded_rank_counts(x[i:i + step], keys[i:i + step], obj[i:i + step], ent_shard, bias_shard,
-                                        b[rank], filt, group)
-        ranks[i:i + step] = (1 + counts[:, 0] + counts[:, 1]).double()
-    ranks = ranks[:real]
+    if world > 1:       # every rank's (padded) queries to every rank, once
+        x_all, key_all, obj_all = _gather(x, group, world), _gather(keys, group, world), _gather(obj, group, world)
+    else:
+        x_all, key_all, obj_all = x.contiguous(), keys, obj
+    total, n_local = x_all.size(0), ent_shard.size(0)
+    target = torch.zeros(total, dtype=torch.float32, device=dev)
+    counts = torch.zeros((total, 3), dtype=torch.int64, device=dev)
+    if total > 0 and n_local > 0:
+        _native.score_target(x_all, ent_shard, bias_shard, obj_all, ent_row0=b[rank], out=target)
+    if world > 1:
+        dist.all_reduce(target, op=dist.ReduceOp.SUM, group=group)   # exactly one rank holds each target entity
+    step = total if not batch_size else int(batch_size)
+    words = (n_local + 31) // 32
+    whole = total * words * 4 <= (512 << 20)                   # filter bits of all queries at once when they fit
+    mask_all = _native.filter_mask(key_all, filt.keys, filt.ptr, filt.tails, n_local, ent_row0=b[rank]) \
+        if (whole and total > 0 and n_local > 0) else None
+    for i in range(0, total, max(step, 1)):
+        if n_local == 0:
+            break
+        mask = mask_all[i:i + step] if mask_all is not None else _native.filter_mask(
+            key_all[i:i + step], filt.keys, filt.ptr, filt.tails, n_local, ent_row0=b[rank])
+        _native.score_rank(x_all[i:i + step], ent_shard, bias_shard, obj_all[i:i + step], target[i:i + step], mask=mask,
+                           ent_row0=b[rank], counts=counts[i:i + step])
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    mine = counts[rank * per:(rank + 1) * per]
+    ranks = (1 + mine[:, 0] + mine[:, 1]).double()[:real]
     sums = torch.zeros(13, dtype=torch.float64, device=dev)    # count, sum rank, sum 1/rank, hits@1..10
     sums[0] = real
     if real > 0:
