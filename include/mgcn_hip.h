@@ -100,7 +100,12 @@ int mgcn_filter_index_build(int64_t num_triples, const int64_t *triples_host, in
  *   slot_dst_host [2E] int32     destination node of each slot, bit 31 = half;
  *   mirror_host [2E] int32       slot of the reverse edge ((e + E) mod 2E) of each slot's edge: the edges leaving n
  *                                in half h are the reverses of the edges entering n in half 1-h, so by-SOURCE sums
- *                                walk the destination runs / hub chunks of the other half through this map;
+ *                                walk the destination runs / hub chunks of the other half through this map.
+ *                                Needs src[e + E] == dst[e] && dst[e + E] == src[e] for every e < E (the loader's
+ *                                list, data_loader.py:143-149); the feeder CHECKS it and, for a list that is not
+ *                                mirror-symmetric (the operator seam model.py:82-101 accepts any list), fills mirror
+ *                                with -1: everything else stays valid (forward, gee, grel), but gx must not be
+ *                                requested from mgcn_aggregate_bwd with such a map (the Python seam raises);
  *   typeptr_host [num_rel_rows+1] int32, typeslots_host [2E] int32
  *                                all slots (ascending) grouped by relation-table row.
  * Fails with MGCN_EINVAL if an endpoint is outside [0,N) or a type outside [0,num_rel_rows-1): the last row of the

@@ -196,6 +196,10 @@ def aggregate_bwd(csr, x, rel, ee, g, want_gx=True, want_gee=True, want_grel=Tru
     _same_device(csr.rowptr, x, rel, ee, g)
     if not csr.has_backward:
         raise NativeError('aggregate_bwd: graph was prepared without the backward indices')
+    if want_gx and not csr.mirrored:
+        raise NativeError('aggregate_bwd: the edge list is not mirror-symmetric (edge e + E is not the reverse of edge e, '
+                          'data_loader.py:143-149), so the gradient w.r.t. the layer input cannot be formed from the '
+                          'destination runs; forward, per-edge and relation gradients are unaffected')
     if g.size(0) != N or g.size(1) < 2 * D:
         raise NativeError('aggregate_bwd: g %s too small' % (tuple(g.shape),))
     if x.size(0) != N or tuple(rel.shape) != (csr.num_rel_rows, D) or not rel.is_contiguous():
@@ -245,7 +249,7 @@ def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, o
 
 def fused_supported(d_in, d_out):
     """Shapes the one-launch layer kernel handles (else: aggregate_fwd + dense_bn_tanh_fwd)."""
-    return (os.environ.get('MGCN_FUSED', '1') != '0' and d_in % 4 == 0 and d_in <= 256 and d_out % 4 == 0
+    return (os.environ.get('MGCN_FUSED', '1') != '0' and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0
             and d_out <= 208)
 
 

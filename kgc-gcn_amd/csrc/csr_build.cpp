@@ -114,9 +114,19 @@ extern "C" int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, in
     // mirror: slot of edge e <-> slot of its reverse edge (e + E) mod 2E. The edges that LEAVE node n in half h are
     // the reverses of the edges that ENTER n in half 1-h, so the by-source sums of the backward walk the same
     // destination runs (and hub chunks) as the forward, through this map.
-    std::vector<int32_t> slot_of(E2);
-    for (int64_t s = 0; s < E2; ++s) slot_of[perm_host[s]] = int32_t(s);
-    for (int64_t s = 0; s < E2; ++s) mirror_host[s] = slot_of[(perm_host[s] + E) % E2];
+    // That only holds for an edge list whose second half is the first half reversed (data_loader.py:143-149 builds
+    // it so). The operator seam (model.py:82-101) accepts ANY [2, 2E] list split in halves by position: for one that
+    // is not mirror-symmetric the forward arrays above are still exact, but there is no such map — mirror is filled
+    // with -1 and the gradient w.r.t. x is refused by the caller (mgcn_aggregate_bwd documents it).
+    bool mirrored = true;
+    for (int64_t e = 0; e < E && mirrored; ++e) mirrored = src[e + E] == dst[e] && dst[e + E] == src[e];
+    if (mirrored) {
+      std::vector<int32_t> slot_of(E2);
+      for (int64_t s = 0; s < E2; ++s) slot_of[perm_host[s]] = int32_t(s);
+      for (int64_t s = 0; s < E2; ++s) mirror_host[s] = slot_of[(perm_host[s] + E) % E2];
+    } else {
+      for (int64_t s = 0; s < E2; ++s) mirror_host[s] = -1;
+    }
     // all slots grouped by relation row, ascending slot id
     std::vector<int32_t> tcur(num_rel_rows + 1, 0);
     std::memset(typeptr_host, 0, sizeof(int32_t) * (num_rel_rows + 1));

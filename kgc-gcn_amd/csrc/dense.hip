@@ -902,21 +902,31 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
   p.m = n_local; p.k = dim; p.ncols = batch;
   set_vec_flags(&p);
   p.tiles_m = int32_t((p.m + BM - 1) / BM);
-  if (p.a_vec && p.b_vec && dim % 4 == 0 && dim <= RANK_MAX_KB * KS && !getenv("MGCN_RANK_TILE")) {
+  // MGCN_RANK_TILE=1 (read once) keeps every shape on the generic tile kernel: tests cover that path with it
+  static const bool force_tile = [] { const char *e = getenv("MGCN_RANK_TILE"); return e && e[0] == '1'; }();
+  if (p.a_vec && p.b_vec && dim % 4 == 0 && dim <= RANK_MAX_KB * KS && !force_tile) {
     // aligned shapes with K <= 256: the query strip stays in LDS (rank_resident_kernel)
     const int nkb = (dim + KS - 1) / KS;
     const size_t lds = (size_t(nkb) * KS * (RANK_NT * 16 + 4) + size_t(RANK_NT) * 16 * 3) * sizeof(float);
-    // more than 64 KB of dynamic LDS: opt in (idempotent, so no state is kept; a failure falls through to the tile kernel)
-    const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    if (!lds_ok) (void)hipGetLastError();
-    if (lds_ok) {
-    const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
-    const int pairs = (p.tiles_m + 1) / 2;
-    const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
-    hipLaunchKernelGGL(rank_resident_kernel, dim3(gx, gy), dim3(512), lds, static_cast<hipStream_t>(stream), p);
-    MGCN_CHECK_LAUNCH("rank_resident_kernel");
-    return MGCN_OK;
+    // more than 64 KB of dynamic LDS needs an opt-in: done ONCE per device (the attribute is sticky), so the call
+    // itself stays free of runtime API work and capturable; a refusal sends every call to the tile kernel
+    static int lds_state[64] = {};   // 0 = not tried, 1 = granted, 2 = refused
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = (dev >= 0 && dev < 64) ? dev : 0;
+    if (lds_state[dev] == 0) {
+      const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+      if (!ok) (void)hipGetLastError();
+      lds_state[dev] = ok ? 1 : 2;
+    }
+    if (lds_state[dev] == 1) {
+      const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
+      const int pairs = (p.tiles_m + 1) / 2;
+      const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
+      hipLaunchKernelGGL(rank_resident_kernel, dim3(gx, gy), dim3(512), lds, static_cast<hipStream_t>(stream), p);
+      MGCN_CHECK_LAUNCH("rank_resident_kernel");
+      return MGCN_OK;
     }
   }
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");

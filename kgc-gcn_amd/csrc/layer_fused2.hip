@@ -1,0 +1,640 @@
+// Fused layer forward (eval), second generation — aggregation + dense step + epilogue in ONE launch (gfx950);
+// replaces model.py:29-30, 99-106, 111-118 for one destination tile per workgroup pass.
+//
+// One 512-thread workgroup per CU (256 VGPRs per wave, 120 KB of LDS), persistent over tiles of BM = 16 * NRT
+// destinations. Two roles, four waves each (one of each per SIMD):
+//   waves 4-7  GATHER  32-lane groups (16 B per lane = 128 columns of the layer input) own BM / 8 consecutive
+//              destinations, whose slots are one contiguous CSR range, walked 8 slots (24 row loads) at a time in
+//              slot order: the same sums as agg_fwd_kernel. A finished row is split EXACTLY into three bf16 pieces
+//              (hi + mid + lo = the f32 value: 3 x 8 significant bits) and written to the stage's LDS image.
+//   waves 0-3  MULTIPLY  acc += A_tile . W with v_mfma_f32_16x16x32_bf16 on the split operands: the six products
+//              hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid (everything down to 2^-16 of |a||w|; what is dropped is
+//              below 2^-24, the rounding of one f32 product), f32 accumulation: f32-faithful at 6/16 of the f32
+//              MFMA's issue time. A wave owns NT/4 column tiles x ALL row tiles of the block tile, so a weight
+//              fragment (three bf16 pieces, pre-split and pre-packed by pack2_kernel, read straight from L2) feeds
+//              6 * NRT MFMAs; the operands are swapped (W as the A operand) so that a lane ends up with four
+//              consecutive output columns of one row: the epilogue (/3, bias, BN eval, tanh: model.py:103-106)
+//              runs on the accumulators and stores 16 bytes per lane.
+// Stage = (mode, 128-column chunk of the input): the gather waves fill LDS image (s + 1) & 1 while the MFMA waves
+// multiply image s & 1; one workgroup barrier per stage, the pipeline runs across modes and tiles.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "mgcn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T2 = 512;
+
+struct Args2 {
+  const int32_t *rowptr;
+  const int4 *rec;
+  const float *x, *rel, *loop_rel, *ee, *loop_edge;
+  const u32x4 *wp;        // packed weights [G][NT][3][64] (8 bf16 per lane)
+  const float *bias, *bn_mean, *bn_var, *bn_gamma, *bn_beta;
+  float *out;
+  int64_t ldx, ldo;
+  int32_t n, d, o, rel_rows;
+  int32_t node0, node1;   // destinations [node0, node1) are this launch's share; out row 0 = node0
+  int32_t ee_sub[2];      // slot-order per-edge table shard: row of (absolute) slot s of half h = s - ee_sub[h]
+  const int2 *hubinfo;    // [2][N] (first chunk, chunk count) or null
+  const float *partial;   // folded hub totals (pre-pass), row (first chunk - chunk0)
+  int32_t chunk0;
+  const float *rw;        // relation projection: rels_weight [D, O] (model.py:107) or null
+  float *rel_out;         // [rel_rows - 1, O]
+  int32_t nch, nkb_last, kbm, G;   // 128-column chunks per mode, k-blocks of the last chunk, k-blocks per mode / tile
+  float bn_eps;
+#ifdef MGCN_DIAG
+  unsigned long long *stamps;   // [grid][2 roles][128]: s_memtime at stage starts / ends of wave 0 (multiply) and wave 4 (gather)
+  int32_t ablate;   // diagnostics build only (tools/ab_fused2.py): bit 0 no slots gathered, bit 1 no MFMAs, bit 2 no epilogue
+#endif
+};
+#ifdef MGCN_DIAG
+#define MGCN_ABLATE(bit) (p.ablate & (bit))
+#define MGCN_STAMP(role, idx)                                                                                      \
+  do {                                                                                                             \
+    if (p.stamps && lane == 0 && (idx) < 128) p.stamps[(int64_t(blockIdx.x) * 2 + (role)) * 128 + (idx)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define MGCN_ABLATE(bit) 0
+#define MGCN_STAMP(role, idx) do {} while (0)
+#endif
+
+__device__ __forceinline__ float tanh2_(float v) {   // as layer_fused.hip: exp2 + rcp, 7 VALU per value
+  const float t = __builtin_amdgcn_exp2f(fabsf(v) * -2.885390081777927f);
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
+}
+
+// Exact three-way split of an f32 into bf16 pieces by truncation: hi = top 8 significant bits, mid = the next 8,
+// lo = the last 8 (each difference is exact, so hi + mid + lo == v bit for bit). Returned as the f32 bit patterns
+// whose upper halves are the bf16 values.
+__device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2);
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) {   // {even >> 16, odd >> 16}
+  return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+
+// wp[((g * NT + ct) * 3 + piece) * 64 + lane] = 8 bf16: W[mode * D + chunk * 128 + 8 * (4 kb + (lane >> 4)) + i]
+// [16 ct + (lane & 15)], i = 0..7, zero outside; g = mode * kbm + 4 * chunk + kb.
+__global__ __launch_bounds__(256) void pack2_kernel(const float *__restrict__ w, u32x4 *__restrict__ wp, int d, int o,
+                                                    int kbm, int nt, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, piece = (idx >> 6) % 3, ct = ((idx >> 6) / 3) % nt, g = (idx >> 6) / (3 * nt);
+  const int mode = g / kbm, kbi = g - mode * kbm, chunk = kbi >> 2, kb = kbi & 3;
+  const int col = ct * 16 + (lane & 15), k0 = chunk * 128 + 8 * (4 * kb + (lane >> 4));
+  uint32_t bits[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    const float v = (k < d && col < o) ? w[(int64_t(mode) * d + k) * o + col] : 0.f;
+    uint32_t h, m, l;
+    split3(v, h, m, l);
+    bits[i] = piece == 0 ? h : piece == 1 ? m : l;
+  }
+  u32x4 r;
+  r.x = pack_hi16(bits[0], bits[1]);
+  r.y = pack_hi16(bits[2], bits[3]);
+  r.z = pack_hi16(bits[4], bits[5]);
+  r.w = pack_hi16(bits[6], bits[7]);
+  wp[idx] = r;
+}
+
+__device__ __forceinline__ float4 f4mul2(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// LDS: [2 stage images][epilogue vectors 5 x 208 floats][relation table, when RELLDS]
+constexpr int EPI_FLOATS = 5 * 208;
+constexpr int REL_LDS_MAX_BYTES = 32 * 1024;
+
+template <int NT, int NRT, bool RELLDS>
+__global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
+  constexpr int BM = NRT * 16;
+  constexpr int PIECE = 16 * BM * 16;   // bytes of one bf16 piece of a stage image: 16 chunk columns x BM rows x 16 B
+  constexpr int BUF = 3 * PIECE;
+  constexpr int RPG = BM / 8;           // destinations per gather group
+  constexpr int UB = RELLDS ? 12 : 8;   // slots per gather batch: 24 row loads in flight per lane group either way
+  constexpr int CH = 32 / UB * UB;      // slots served by one record chunk (lane i: slot cbase + i)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+  float *epi = reinterpret_cast<float *>(lds2 + 2 * BUF);   // [cb | mean | inv | gamma | beta] x 208
+  float *rel_lds = epi + EPI_FLOATS;                         // [rel_rows - 1][D] when RELLDS
+
+  const int bid = int(blockIdx.x), nblk = int(gridDim.x);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nrows = p.node1 - p.node0;
+  const int ntiles = (nrows + BM - 1) / BM;
+  const int my_tiles = (ntiles - bid + nblk - 1) / nblk;   // >= 1 (grid <= ntiles)
+  const int nch = p.nch;
+
+  // once per workgroup: the epilogue's per-column vectors (model.py:103-106) and, when it fits, the relation table
+  for (int c = tid; c < 208; c += T2) {
+    const bool in = c < p.o;
+    epi[c] = (in && p.bias) ? p.bias[c] : 0.f;
+    epi[208 + c] = in ? p.bn_mean[c] : 0.f;
+    epi[416 + c] = in ? __builtin_amdgcn_rsqf(p.bn_var[c] + p.bn_eps) : 0.f;
+    epi[624 + c] = in ? p.bn_gamma[c] : 0.f;
+    epi[832 + c] = in ? p.bn_beta[c] : 0.f;
+  }
+  if (RELLDS) {
+    const int n4 = ((p.rel_rows - 1) * p.d) >> 2;
+    for (int i = tid; i < n4; i += T2)
+      reinterpret_cast<float4 *>(rel_lds)[i] = reinterpret_cast<const float4 *>(p.rel)[i];
+  }
+  __syncthreads();
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------ GATHER
+    const int gtid = tid - 256;
+    const int grp = gtid >> 5, lig = gtid & 31;
+    const int glane0 = lane & 32;
+    const int g_lo = grp * RPG, g_hi = g_lo + RPG;
+    const int qcol = lig >> 1, frot = (qcol >> 1) & 7;
+    const int wbase = qcol * BM * 16 + (lig & 1) * 8;
+    const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
+
+    auto write_row = [&](unsigned char *img, int row, float4 v, bool ok) __attribute__((always_inline)) {
+      uint32_t h[4], m[4], l[4];
+      split3(ok ? v.x : 0.f, h[0], m[0], l[0]);
+      split3(ok ? v.y : 0.f, h[1], m[1], l[1]);
+      split3(ok ? v.z : 0.f, h[2], m[2], l[2]);
+      split3(ok ? v.w : 0.f, h[3], m[3], l[3]);
+      unsigned char *dst = img + wbase + ((row & ~15) + (((row & 15) + frot) & 15)) * 16;
+      *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+      *reinterpret_cast<uint2 *>(dst + PIECE) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+      *reinterpret_cast<uint2 *>(dst + 2 * PIECE) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+    };
+    // lane i of a group holds the row pointer of destination g_lo + i (i <= RPG) and the record of slot beg + i:
+    // both are fetched one (tile, mode) ahead, so a stage starts straight at its row loads.
+    auto rp_of = [&](int it_, int mode_) {
+      int node = p.node0 + (bid + it_ * nblk) * BM + g_lo + (lig <= RPG ? lig : RPG);
+      node = node < p.node1 ? node : p.node1;
+      return p.rowptr[int64_t(mode_) * (p.n + 1) + node];
+    };
+    auto rec_chunk = [&](int cbeg, int end) {   // lane i: record of slot cbeg + i (clamped to the range's last slot)
+      int4 r = make_int4(0, 0, 0, 0);
+      if (end > cbeg) r = p.rec[(cbeg + lig < end) ? cbeg + lig : end - 1];
+      return r;
+    };
+    int currp = rp_of(0, 0);
+    int4 currec = rec_chunk(__shfl(currp, glane0), __shfl(currp, glane0 + RPG));
+    int stage = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+      const int r0 = p.node0 + (bid + it * nblk) * BM;
+      for (int mode = 0; mode < 3; ++mode) {
+        if (mode < 2) {
+          const int myrp = currp;
+          const int4 firstrec = currec;
+          const int ee_sub_mode = p.ee_sub[mode];
+          const bool has_next = mode == 0 || it + 1 < my_tiles;   // next (tile, mode) with records
+          int nrp = 0;
+          if (has_next) nrp = rp_of(mode == 0 ? it : it + 1, mode == 0 ? 1 : 0);
+          bool next_recs_issued = false;
+          int4 nrec = make_int4(0, 0, 0, 0);
+          int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination g_lo + i
+          {
+            const int node = r0 + g_lo + (lig <= RPG ? lig : RPG);
+            if (p.hubinfo && lig < RPG && node < p.node1) myhub = p.hubinfo[int64_t(mode) * p.n + node];
+          }
+          const int beg = __shfl(myrp, glane0), end = MGCN_ABLATE(1) ? beg : __shfl(myrp, glane0 + RPG);
+          for (int chunk = 0; chunk < nch; ++chunk, ++stage) {
+            if (wave == 4) MGCN_STAMP(1, 2 * stage);
+            unsigned char *img = lds2 + (stage & 1) * BUF;
+            const int coff_ = chunk * 128 + lig * 4;
+            const bool col_ok = coff_ < p.d;
+            const int coff = col_ok ? coff_ : 0;   // lanes past the row width repeat columns 0-3 and store zeros
+            const float *xb = p.x + coff, *relb = (RELLDS ? rel_lds : p.rel) + coff, *eeb = p.ee + coff;
+            int4 myrec = firstrec;
+            int row = g_lo, nb = __shfl(myrp, glane0 + 1);
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto flush = [&]() __attribute__((always_inline)) {   // the run of destination `row` is complete (group-uniform)
+              if (p.hubinfo) {     // a hub's own run is empty: its folded total sits in the row of its first chunk
+                const int first = __shfl(myhub.x, glane0 + (row - g_lo)), cnt = __shfl(myhub.y, glane0 + (row - g_lo));
+                if (cnt > 0) {
+                  const float4 ps = *reinterpret_cast<const float4 *>(p.partial + int64_t(first - p.chunk0) * p.d + coff);
+                  sum = make_float4(sum.x + ps.x, sum.y + ps.y, sum.z + ps.z, sum.w + ps.w);
+                }
+              }
+              write_row(img, row, sum, col_ok);
+              sum = make_float4(0.f, 0.f, 0.f, 0.f);
+              ++row;
+            };
+            int cbase = beg;                                   // first slot of the record chunk held in myrec
+            for (int s = beg; s < end; s += UB) {
+              if (s >= cbase + CH) {                           // group-uniform: next record chunk of a long range
+                cbase += CH;
+                myrec = rec_chunk(cbase, end);
+              }
+              int rsrc[UB], rtyp[UB], rnrm[UB];
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                const int from = glane0 + (((s + u < end) ? s + u : end - 1) - cbase);
+                rsrc[u] = __shfl(myrec.x, from);
+                rtyp[u] = __shfl(myrec.y, from);
+                rnrm[u] = __shfl(myrec.z, from);
+              }
+              float4 xv[UB], rv[UB], ev[UB];
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                xv[u] = *reinterpret_cast<const float4 *>(xb + uint64_t(uint32_t(rsrc[u])) * ldx32);
+                if (!RELLDS) rv[u] = *reinterpret_cast<const float4 *>(relb + uint64_t(uint32_t(rtyp[u])) * d32);
+                const uint32_t erow = uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
+                ev[u] = *reinterpret_cast<const float4 *>(eeb + uint64_t(erow) * d32);
+              }
+              if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s first records
+                next_recs_issued = true;
+                if (has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + RPG));
+              }
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                if (s + u < end) {
+                  while (s + u >= nb) {
+                    flush();
+                    nb = __shfl(myrp, glane0 + (row - g_lo) + 1);
+                  }
+                  const float4 rr = RELLDS ? *reinterpret_cast<const float4 *>(relb + uint32_t(rtyp[u]) * d32) : rv[u];
+                  const float4 m = f4mul2(f4mul2(xv[u], rr), ev[u]);
+                  const float wgt = __int_as_float(rnrm[u]);
+                  sum = make_float4(sum.x + m.x * wgt, sum.y + m.y * wgt, sum.z + m.z * wgt, sum.w + m.w * wgt);
+                }
+              }
+            }
+            if (!next_recs_issued) {
+              next_recs_issued = true;
+              if (has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + RPG));
+            }
+            while (row < g_hi) flush();  // last run, then zero rows for destinations without slots
+            if (wave == 4) MGCN_STAMP(1, 2 * stage + 1);
+            __syncthreads();             // end of stage: image stage & 1 is complete
+          }
+          currp = nrp;
+          currec = nrec;
+        } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101
+          for (int chunk = 0; chunk < nch; ++chunk, ++stage) {
+            if (wave == 4) MGCN_STAMP(1, 2 * stage);
+            unsigned char *img = lds2 + (stage & 1) * BUF;
+            const int coff_ = chunk * 128 + lig * 4;
+            const bool col_ok = coff_ < p.d;
+            const int coff = col_ok ? coff_ : 0;
+            const float4 lr = *reinterpret_cast<const float4 *>(p.loop_rel + coff);
+            const float4 le = *reinterpret_cast<const float4 *>(p.loop_edge + coff);
+            float4 xs[RPG];
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) {
+              const int node = (r0 + g_lo + i < p.node1) ? r0 + g_lo + i : p.node1 - 1;   // rows past the range: computed, never stored
+              xs[i] = *reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < RPG; ++i) write_row(img, g_lo + i, f4mul2(f4mul2(xs[i], lr), le), col_ok);
+            if (wave == 4) MGCN_STAMP(1, 2 * stage + 1);
+            __syncthreads();
+          }
+        }
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------ MULTIPLY
+    constexpr int Q = NT / 4, R = NT % 4;
+    constexpr int QF = Q > 0 ? Q : 1;
+    constexpr int NX = R * NRT;                      // single (column tile, row tile) units shared out round-robin
+    constexpr int XE = (NX + 3) / 4;                 // ... at most XE per wave
+    constexpr int XF = XE > 0 ? XE : 1;
+    constexpr int XW = (R == 1) ? 1 : XF;            // weight fragments for them (R == 1: all in one column tile)
+    const int w = wave;
+    const int r = lane & 15, gq = lane >> 4;
+    const int ct0 = w * Q;
+    int xct[XF], xrt[XF];
+    bool xok[XF];
+#pragma unroll
+    for (int j = 0; j < XF; ++j) {
+      const int e = 4 * j + w;
+      xok[j] = XE > 0 && e < NX;
+      xct[j] = xok[j] ? 4 * Q + e / NRT : 0;
+      xrt[j] = xok[j] ? e % NRT : -1;
+    }
+    const int G = p.G;
+    auto wload = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], int g) {
+      const u32x4 *base = p.wp + (int64_t(g) * NT) * 3 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < Q; ++t) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wq[t][pc] = base[((ct0 + t) * 3 + pc) * 64];
+      }
+      if (XE > 0) {
+#pragma unroll
+        for (int j = 0; j < XW; ++j) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) wx[j][pc] = base[(xct[j] * 3 + pc) * 64];
+        }
+      }
+    };
+    // Three NAMES for two live fragment sets: a k-block first issues the loads of the NEXT k-block into the set that
+    // died one k-block ago, then multiplies with its own (loaded one k-block = ~100 MFMAs earlier). G is a multiple
+    // of 3, so the rotation closes per tile with no conditional code between the k-blocks.
+    u32x4 wq0[QF][3], wx0[XW][3], wq1[QF][3], wx1[XW][3], wq2[QF][3], wx2[XW][3];
+
+    f32x4 acc[NRT][QF], accx[XF];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+        for (int t = 0; t < QF; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < XF; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // lane holds out[row = 16 rt + r][16 ct + 4 gq .. + 3] (operands swapped: W is the MFMA's A operand)
+    auto store_unit = [&](f32x4 a, int prow, int col, const float4 &mean, const float4 &inv, const float4 &gam,
+                          const float4 &bet, const float4 &cb) {
+      if (prow < nrows) {
+        constexpr float third = 1.0f / 3.0f;   // (sum of the three modes) / 3, model.py:103, as a multiplication (<= 1 ulp)
+        float4 v = make_float4(a[0] * third + cb.x, a[1] * third + cb.y, a[2] * third + cb.z, a[3] * third + cb.w);
+        v = make_float4(tanh2_((v.x - mean.x) * inv.x * gam.x + bet.x), tanh2_((v.y - mean.y) * inv.y * gam.y + bet.y),
+                        tanh2_((v.z - mean.z) * inv.z * gam.z + bet.z), tanh2_((v.w - mean.w) * inv.w * gam.w + bet.w));
+        *reinterpret_cast<float4 *>(p.out + int64_t(prow) * p.ldo + col) = v;
+      }
+    };
+    auto epilogue = [&](int tile) {
+      const int prow0 = tile * BM + r;
+      auto column_tile = [&](int ct, auto &&body) {
+        const int col = ct * 16 + 4 * gq;
+        if (col < p.o) {
+          const float4 cb = *reinterpret_cast<const float4 *>(epi + col);
+          const float4 mean = *reinterpret_cast<const float4 *>(epi + 208 + col);
+          const float4 inv = *reinterpret_cast<const float4 *>(epi + 416 + col);
+          const float4 gam = *reinterpret_cast<const float4 *>(epi + 624 + col);
+          const float4 bet = *reinterpret_cast<const float4 *>(epi + 832 + col);
+          body(col, mean, inv, gam, bet, cb);
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < Q; ++t) {
+        column_tile(ct0 + t, [&](int col, const float4 &mean, const float4 &inv, const float4 &gam, const float4 &bet,
+                                 const float4 &cb) {
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) store_unit(acc[rt][t], prow0 + rt * 16, col, mean, inv, gam, bet, cb);
+        });
+      }
+      if (XE > 0) {
+#pragma unroll
+        for (int j = 0; j < XF; ++j) {
+          if (xok[j]) {
+            column_tile(xct[j], [&](int col, const float4 &mean, const float4 &inv, const float4 &gam, const float4 &bet,
+                                    const float4 &cb) { store_unit(accx[j], prow0 + xrt[j] * 16, col, mean, inv, gam, bet, cb); });
+          }
+        }
+      }
+    };
+
+    // (Every workgroup walks the k-blocks in the same order: a row's sum must not depend on which workgroup or which
+    // launch — full or one rank's destination range — computes it. Rotating the order per workgroup was tried to
+    // spread the weight reads over the L2 channels: no gain, and it breaks that bit-identity.)
+    auto rotated = [&](int kb_, int) { return kb_; };
+    int kb = 0, chunk = 0, stage = 0;
+    int nkb_ = 0, nchunk = 0, nmode = 0;          // the k-block after the current one: (mode, chunk, ordinal)
+    auto advance_next = [&]() {
+      const int n = (nchunk == nch - 1) ? p.nkb_last : 4;
+      if (++nkb_ == n) {
+        nkb_ = 0;
+        if (++nchunk == nch) {
+          nchunk = 0;
+          nmode = nmode == 2 ? 0 : nmode + 1;
+        }
+      }
+    };
+    auto gindex = [&]() { return nmode * p.kbm + 4 * nchunk + rotated(nkb_, nchunk); };
+    wload(wq0, wx0, gindex());
+    advance_next();
+    // all_rel = rel @ rels_weight (model.py:107) while the first stage is being gathered: one item = one relation
+    // row x 64 columns per wave, with small_matmul_kernel's arithmetic (K in quarters, sequential fmaf chains,
+    // the four partial sums added in order), so the values are bit-identical to the separate launch.
+    if (p.rel_out) {
+      const int rows = p.rel_rows - 1, k = p.d, n = p.o;
+      const int ngrp = (n + 63) / 64, items = rows * ngrp;
+      const int kper = (k + 3) / 4;
+      // items dealt wave-major (wave 0 of every workgroup first): at most one item per workgroup for up to 4 * grid items
+      for (int item = w * nblk + bid; item < items; item += nblk * 4) {
+        const int row = item / ngrp, col = (item - row * ngrp) * 64 + lane;
+        const bool ok = col < n;
+        const float *ap = p.rel + int64_t(row) * k;
+        const float *bp = p.rw + (ok ? col : 0);
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int UR = 8;                    // 4 x 8 x 2 loads in flight, then the fmaf chains (K order kept per quarter)
+        for (int i0 = 0; i0 < kper; i0 += UR) {
+          float av[4][UR], bv[4][UR];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int k1 = (qd * kper + kper < k) ? qd * kper + kper : k;
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+              const int kk = qd * kper + i0 + u;
+              const int kc = (i0 + u < kper && kk < k1) ? kk : 0;
+              av[qd][u] = ap[kc];
+              bv[qd][u] = bp[int64_t(kc) * n];
+            }
+          }
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int k1 = (qd * kper + kper < k) ? qd * kper + kper : k;
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+              const int kk = qd * kper + i0 + u;
+              if (i0 + u < kper && kk < k1) a4[qd] = fmaf(av[qd][u], bv[qd][u], a4[qd]);
+            }
+          }
+        }
+        if (ok) p.rel_out[int64_t(row) * n + col] = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+      }
+    }
+
+    auto kblock = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], u32x4 (&nq)[QF][3], u32x4 (&nx)[XW][3]) {
+      wload(nq, nx, gindex());           // the k-block after this one (wraps into the next tile: same weights)
+      advance_next();
+      const int nkb_c = (chunk == nch - 1) ? p.nkb_last : 4;
+      if (kb == 0) {
+        __syncthreads();                // the stage's image is complete
+        if (wave == 0) MGCN_STAMP(0, 2 * stage);
+      }
+      const int qc = 4 * rotated(kb, chunk) + gq;
+      const unsigned char *ap = lds2 + (stage & 1) * BUF + (qc * BM + ((r + ((qc >> 1) & 7)) & 15)) * 16;
+      // the six products, small terms first: (w piece, a piece) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
+      constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, AP[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        if (Q > 0 && !MGCN_ABLATE(2)) {
+          bf16x8 a[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + rt * 256));
+#pragma unroll
+          for (int pr = 0; pr < 6; ++pr) {
+#pragma unroll
+            for (int t = 0; t < Q; ++t)
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[t][WP[pr]]), a[AP[pr]],
+                                                                   acc[rt][t], 0, 0, 0);
+          }
+        }
+      }
+      if (XE > 0) {   // this wave's single units: their own fragment reads (row tile = a wave-uniform offset), no branches
+#pragma unroll      // inside the row-tile loop above
+        for (int j = 0; j < XF; ++j) {
+          if (xok[j]) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+              a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + xrt[j] * 256));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+              accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[XW == 1 ? 0 : j][WP[pr]]),
+                                                                a[AP[pr]], accx[j], 0, 0, 0);
+          }
+        }
+      }
+      if (++kb == nkb_c) {
+        if (wave == 0) MGCN_STAMP(0, 2 * stage + 1);
+        kb = 0;
+        ++stage;
+        if (++chunk == nch) chunk = 0;
+      }
+    };
+    for (int it = 0; it < my_tiles; ++it) {
+      zero_acc();
+      for (int g0 = 0; g0 < G; g0 += 3) {
+        kblock(wq0, wx0, wq1, wx1);
+        kblock(wq1, wx1, wq2, wx2);
+        kblock(wq2, wx2, wq0, wx0);
+      }
+      if (!MGCN_ABLATE(4)) epilogue(bid + it * nblk);
+    }
+  }
+}
+
+template <int NT, int NRT, bool RELLDS>
+int launch2(const Args2 &p, int grid, hipStream_t st) {
+  constexpr size_t lds_bytes = size_t(2) * 3 * 16 * (NRT * 16) * 16 + EPI_FLOATS * 4 + (RELLDS ? REL_LDS_MAX_BYTES : 0);
+  static bool attr_set[64] = {};   // per device, set once (the attribute is sticky): not re-done per call
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_fused2_kernel<NT, NRT, RELLDS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)) != hipSuccess)
+      return mgcn::fail(MGCN_ELAUNCH, "layer_fused2: cannot reserve %zu bytes of LDS", lds_bytes);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((layer_fused2_kernel<NT, NRT, RELLDS>), dim3(unsigned(grid)), dim3(T2), lds_bytes, st, p);
+  MGCN_CHECK_LAUNCH("layer_fused2_kernel");
+  return MGCN_OK;
+}
+
+int pick_nt2(int o) { return o <= 32 ? 2 : o <= 64 ? 4 : o <= 128 ? 8 : 13; }
+
+struct Shape2 {
+  int nch, nkb_last, kbm, G;
+};
+Shape2 shape2(int d) {
+  Shape2 s;
+  s.nch = (d + 127) / 128;
+  const int wlast = d - 128 * (s.nch - 1);
+  s.nkb_last = (wlast + 31) / 32;
+  s.kbm = 4 * (s.nch - 1) + s.nkb_last;
+  s.G = 3 * s.kbm;
+  return s;
+}
+
+#ifdef MGCN_DIAG
+unsigned long long *diag_stamps() {
+  static unsigned long long *buf = nullptr;
+  if (!buf && getenv("MGCN_FUSED_STAMPS")) {
+    if (hipMalloc(&buf, 1024 * 2 * 128 * 8) != hipSuccess) buf = nullptr;
+    else (void)hipMemset(buf, 0, 1024 * 2 * 128 * 8);
+  }
+  return buf;
+}
+#endif
+
+}  // namespace
+
+#ifdef MGCN_DIAG
+extern "C" int mgcn_diag_read_stamps(unsigned long long *host_out) {   // [1024][2][128], of the LAST fused launch
+  unsigned long long *b = diag_stamps();
+  if (!b) return 1;
+  return hipMemcpy(host_out, b, 1024 * 2 * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
+
+namespace mgcn {
+
+bool fused2_takes(int32_t dim_in, int32_t dim_out) {
+  return dim_in > 0 && dim_in % 4 == 0 && dim_in <= 1024 && dim_out > 0 && dim_out % 4 == 0 && dim_out <= 208;
+}
+
+size_t fused2_packed_bytes(int32_t dim_in, int32_t dim_out) {
+  return size_t(shape2(dim_in).G) * pick_nt2(dim_out) * 3 * 64 * 16;
+}
+
+int fused2_pack(int32_t dim_in, int32_t dim_out, const float *w_dev, void *wp_dev, void *stream) {
+  const Shape2 s = shape2(dim_in);
+  const int nt = pick_nt2(dim_out);
+  const int total = s.G * nt * 3 * 64;
+  hipLaunchKernelGGL(pack2_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w_dev,
+                     reinterpret_cast<u32x4 *>(wp_dev), dim_in, dim_out, s.kbm, nt, total);
+  MGCN_CHECK_LAUNCH("pack2_kernel");
+  return MGCN_OK;
+}
+
+int fused2_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
+                  const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
+                  const float *loop_rel_dev, const float *ee_dev, const float *loop_edge_dev, const void *wp_dev,
+                  const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev, const float *bn_gamma_dev,
+                  const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
+                  int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
+                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, void *stream) {
+  const Shape2 s = shape2(dim_in);
+  Args2 p = {};
+  p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
+  p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;
+  p.wp = reinterpret_cast<const u32x4 *>(wp_dev);
+  p.bias = bias_dev; p.bn_mean = bn_mean_dev; p.bn_var = bn_var_dev; p.bn_gamma = bn_gamma_dev; p.bn_beta = bn_beta_dev;
+  p.out = out_dev; p.ldx = ldx; p.ldo = ldo;
+  p.n = int32_t(num_nodes); p.d = dim_in; p.o = dim_out; p.rel_rows = num_rel_rows;
+  p.node0 = int32_t(node_begin); p.node1 = int32_t(node_end);
+  p.ee_sub[0] = int32_t(ee_sub_in); p.ee_sub[1] = int32_t(ee_sub_out);
+  p.hubinfo = reinterpret_cast<const int2 *>(hubinfo_dev); p.partial = partial_dev; p.chunk0 = int32_t(chunk_begin);
+  p.rw = rel_out_dev ? rels_weight_dev : nullptr; p.rel_out = rel_out_dev;
+  p.nch = s.nch; p.nkb_last = s.nkb_last; p.kbm = s.kbm; p.G = s.G;
+  p.bn_eps = bn_eps;
+#ifdef MGCN_DIAG
+  if (const char *ab = getenv("MGCN_FUSED_ABLATE")) p.ablate = atoi(ab);
+  p.stamps = diag_stamps();
+#endif
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  constexpr int NRT = 5;
+  const int ntiles = int((node_end - node_begin + NRT * 16 - 1) / (NRT * 16));
+  const int grid = ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus;   // persistent: one workgroup per CU
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // the relation table rides in LDS when it fits beside the stage images (a third of the gather's row loads)
+  const bool rel_lds = rel_dev && size_t(num_rel_rows - 1) * dim_in * 4 <= size_t(REL_LDS_MAX_BYTES);
+  switch (pick_nt2(dim_out) * 2 + (rel_lds ? 1 : 0)) {
+    case 4: return launch2<2, NRT, false>(p, grid, st);
+    case 5: return launch2<2, NRT, true>(p, grid, st);
+    case 8: return launch2<4, NRT, false>(p, grid, st);
+    case 9: return launch2<4, NRT, true>(p, grid, st);
+    case 16: return launch2<8, NRT, false>(p, grid, st);
+    case 17: return launch2<8, NRT, true>(p, grid, st);
+    case 26: return launch2<13, NRT, false>(p, grid, st);
+    default: return launch2<13, NRT, true>(p, grid, st);
+  }
+}
+
+}  // namespace mgcn

@@ -24,6 +24,9 @@ class GraphCSR(object):
         self.num_edges_half = int(edge_index.size(1)) // 2
         self.num_rel_rows = int(num_rel_rows)
         self.has_backward = with_backward
+        # False for an edge list whose second half is not the first half reversed (only possible at the operator
+        # seam): forward, gee and grel are exact, the by-source sums of gx have no mirror map to walk (include (1))
+        self.mirrored = bool(with_backward and (host['mirror'].numel() == 0 or int(host['mirror'][0]) >= 0))
         for k in self._FIELDS:
             setattr(self, k, host[k].to(device) if k in host else None)
         self._inv_perm = None

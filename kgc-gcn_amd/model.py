@@ -119,40 +119,13 @@ class MGCNConv(nn.Module):
         return self.derived_weights()[0]
 
     def _two_launch_layer(self, csr, x, rels, ee, ee_in_slot_order, all_ent):
-        """Aggregation launch + dense launch. Opt-in experiment MGCN_PIPELINE_CHUNKS = C > 1: rows cut into C chunks,
-        the two kinds of launch on two streams, chunk c's dense step waiting only for chunk c's aggregation.
-        Measured on MI355X / ROCm 7.2 it LOSES: every cross-stream dependency costs ~30 us inside a hipGraph
-        (373 us -> 542 / 820 / 1403 us per step at C = 4 / 8 / 16), so the default is one chunk."""
-        import os
-        n, d = x.size(0), self.in_channels
+        """Aggregation launch + dense launch (shapes the one-launch kernel does not take, tables in edge-id order)."""
         bn = self.ent_bn
-        agg = torch.empty((n, 3 * d), dtype=torch.float32, device=x.device)
+        agg = torch.empty((x.size(0), 3 * self.in_channels), dtype=torch.float32, device=x.device)
         w = self._wcat if _capturing(x) else self.stacked_weight()
-        le, lr = self.loop_edge.reshape(-1), self.loop_rel.reshape(-1)
-        chunks = int(os.environ.get('MGCN_PIPELINE_CHUNKS', '1'))   # measured: > 1 is slower on ROCm 7.2 (DESIGN.md §4)
-        if chunks <= 1 or n < 64 * chunks:
-            _native.aggregate_fwd(csr, x, rels, ee, ee_in_slot_order, le, agg, loop_rel=lr)
-            _native.dense_bn_tanh_fwd(agg, w, self.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
-            return
-        main = torch.cuda.current_stream(x.device)
-        if getattr(self, '_side_stream', None) is None or self._side_stream.device != x.device:
-            self._side_stream = torch.cuda.Stream(device=x.device)
-        side = self._side_stream
-        side.wait_stream(main)                                  # operands produced on the main stream are ready
-        step = ((n + chunks - 1) // chunks + 31) // 32 * 32     # whole 32-row tiles per chunk
-        for lo in range(0, n, step):
-            hi = min(lo + step, n)
-            with torch.cuda.stream(side):
-                _native.aggregate_fwd(csr, x, rels, ee, ee_in_slot_order, le, agg, loop_rel=lr, node_range=(lo, hi))
-                done = torch.cuda.Event()
-                done.record(side)
-            main.wait_event(done)
-            _native.dense_bn_tanh_fwd(agg[lo:hi], w, self.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                                      bn.eps, all_ent[lo:hi])
-        side.wait_stream(main)                                  # `agg` may be freed/reused only after its readers ran
-        if not _capturing(x):
-            for t in (agg, x, rels, ee, w):
-                t.record_stream(side)
+        _native.aggregate_fwd(csr, x, rels, ee, ee_in_slot_order, self.loop_edge.reshape(-1), agg,
+                              loop_rel=self.loop_rel.reshape(-1))
+        _native.dense_bn_tanh_fwd(agg, w, self.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent)
 
     def compute_norm(self, edge_index, num_ent):
         """deg^-1/2[row] * deg^-1/2[col], degrees counted by source (model.py:72-80). The layer itself reads
@@ -192,6 +165,12 @@ class MGCNConv(nn.Module):
             # (rels @ W)[:-1] drops the self-loop row, so the projection needs no concatenation (model.py:107)
             return all_ent, _native.matmul(rels_embs.contiguous(), self.rels_weight)
 
+        if x.requires_grad and not csr.mirrored:
+            # the loader's list is mirror-symmetric (data_loader.py:143-149); the seam accepts any list (model.py:88-90)
+            raise _native.NativeError(
+                'MGCNConv.forward: edge_index[:, E:] is not edge_index[:, :E] reversed, so the gradient w.r.t. x cannot be '
+                'formed by the HIP backward (it walks destination runs through the reverse-edge map); the forward of '
+                'such a list is supported without autograd')
         rels = torch.cat([rels_embs, self.loop_rel], dim=0)
         ee = edge_embs if ee_in_slot_order else edge_embs.index_select(0, csr.perm)
         agg = _AggregateFn.apply(x, rels, ee.contiguous(), csr)

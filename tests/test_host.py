@@ -462,6 +462,8 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         msg = lib.mgcn_last_error().decode()
         assert rc == 1, (name, rc, msg)
         assert re.search(pattern, msg), (name, msg)
-    assert lib.mgcn_packed_weights_bytes(100, 200) == 3 * 7 * 13 * 64 * 16
+    # second-generation fused layer: 3 modes x 4 k-blocks of 32 (100 -> 128 columns) x 13 column tiles x 3 bf16 pieces x 1 KiB
+    assert lib.mgcn_packed_weights_bytes(100, 200) == 3 * 4 * 13 * 3 * 64 * 16
+    assert lib.mgcn_packed_weights_bytes(200, 200) == 3 * 7 * 13 * 3 * 64 * 16   # 128 + 72 columns: 4 + 3 k-blocks
     assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
     assert lib.mgcn_score_bce_partials(128, 40943) == 1280

@@ -1,0 +1,65 @@
+"""Stage timeline of the fused layer kernel from the diagnostics build's s_memtime stamps (not product code).
+MGCN_LIB=.../libmgcn_hip_diag.so MGCN_FUSED_STAMPS=1 python tools/fused2_timeline.py [layer: 0|1]"""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    which = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    pkg = importlib.import_module('kgc-gcn_amd')
+    nat = pkg._native
+    dev = torch.device('cuda:0')
+    shape = bench.SHAPES['wn18rr']
+    N, R, E = shape['N'], shape['R'], shape['E']
+    ei, ea = bench.synth_graph(shape, seed=0)
+    graph = pkg.Graph(edge_index=ei, edge_attr=ea)
+    graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
+    graph.to(dev)
+    csr = graph.csr(2 * R + 1)
+    D, O = (100, 200) if which == 0 else (200, 200)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(N, D, generator=g) * 0.3).to(dev)
+    rel = (torch.randn(2 * R, D, generator=g) * 0.5).to(dev)
+    layer = pkg.model.MGCNConv(D, O, 2 * R).to(dev).eval()
+    ee = (torch.randn(2 * E, D, generator=g) * 0.5).to(dev)
+    bn = layer.ent_bn
+    wcat, wpack = layer.derived_weights()
+    out = torch.empty((N, O), device=dev)
+    rel_out = torch.empty((2 * R, O), device=dev)
+    with torch.no_grad():
+        for _ in range(30):
+            nat.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), ee, True, layer.loop_edge.reshape(-1), wpack, O,
+                                layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                                rels_weight=layer.rels_weight.detach(), rel_out=rel_out)
+        torch.cuda.synchronize()
+    buf = np.zeros((1024, 2, 128), dtype=np.uint64)
+    fn = nat.lib().mgcn_diag_read_stamps
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p]
+    assert fn(buf.ctypes.data) == 0
+    st = buf[:256].astype(np.int64)
+    t0 = st[:, :, 0].min()
+    nst = int((st[0, 1] > 0).sum()) // 2
+    print('stages per block: %d; launch span %d cycles' % (nst, st.max() - t0))
+    for b in (0, 100, 255):
+        print('block', b)
+        for s in range(nst):
+            g0, g1, m0, m1 = st[b, 1, 2 * s], st[b, 1, 2 * s + 1], st[b, 0, 2 * s], st[b, 0, 2 * s + 1]
+            print('  stage %2d  gather start %7d work %6d | multiply start %7d work %6d' % (s, g0 - t0, g1 - g0, m0 - t0, m1 - m0))
+    gw = (st[:, 1, 1:2 * nst:2] - st[:, 1, 0:2 * nst:2])
+    mw = (st[:, 0, 1:2 * nst:2] - st[:, 0, 0:2 * nst:2])
+    print('median gather work per stage :', np.median(gw, axis=0).astype(int).tolist())
+    print('median multiply work per stage:', np.median(mw, axis=0).astype(int).tolist())
+    print('median end (cycles): gather %d multiply %d' % (np.median(st[:, 1, 2 * nst - 1] - t0), np.median(st[:, 0, 2 * nst - 1] - t0)))
+
+
+if __name__ == '__main__':
+    main()
