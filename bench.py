@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — aggregated edges/sec of the full-graph M-GCN encoder forward (+ filtered-MRR eval wall-clock).
+"""bench.py — aggregated edges/sec of the full-graph M-GCN encoder forward (+ filtered-MRR evaluation wall-clock).
 
-Workload (BASELINE.json configs[1]): synthetic graph of the public WN18RR shape (N=40 943, R=11,
-E=86 835 train triples -> 173 670 directed edges + N self loops per layer), 2 layers 100 -> 200 -> 200,
-f32, eval mode. A "step" is one encoder forward over the whole graph: per layer one aggregation launch,
-one f32-MFMA dense+BN+tanh launch and the small relation projection. Inputs (tables, CSR, weights) are
-resident in HBM before the timed region. One JSON line on stdout (rank 0).
+Headline workload (BASELINE.json configs[1]): synthetic graph of the public WN18RR shape (N=40 943, R=11, E=86 835
+train triples -> 173 670 directed edges + N self loops per layer), 2 layers 100 -> 200 -> 200, eval mode. A "step" is
+one encoder forward over the whole graph: one fused launch per layer (aggregation + dense step + BN + tanh + relation
+projection), replayed from a hipGraph. Inputs (tables, CSR, weights) are resident in HBM before the timed region.
+The same run also reports, in sub-objects of the ONE JSON line printed by rank 0:
+  kernels / roofline   per-launch device time (HIP events on the launch stream) priced against BOTH roofs (SURVEY §8d
+                       bytes / 8 TB/s, and the dense step's flops / MFMA peak), PMC traffic from profiles/;
+  fb15k237             the same step on the FB15k-237 shape (BASELINE configs[2]) with its own kernels and CPU baseline;
+  eval                 full filtered-MRR evaluation wall-clock on the WN18RR shape (three forms) and, under
+                       eval.fb15k237, BASELINE configs[3]: the FB15k-237-shape evaluation with the entity table sharded
+                       over all ranks (RCCL) next to the same evaluation on ONE rank, so the N-GPU gain reads off one line;
+  cpu_baseline         the oracle on this box's host cores (N = 1 only).
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 run under torch.distributed.run (one rank per GPU).
+`python bench.py --gpus N --steps K --warmup W`. For N > 1 either run it under torch.distributed.run (one rank per
+GPU) or plainly: without WORLD_SIZE in the environment it starts the N ranks itself (a torch.distributed.run child,
+before this process touches the GPU) and relays their output.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 import types
@@ -28,7 +39,9 @@ SHAPES = {  # public dataset shapes
     'fb15k237': dict(N=14541, R=237, E=272115, n_eval=20466),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA: what the algorithmic flops of the dense step cost in f32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA: what the kernel's six split products are issued on
+KERNEL_SOURCES = ('layer_fused2.hip', 'layer_fused.hip', 'aggregate.hip')
 
 
 def synth_graph(shape, seed=0, zipf=0.0):
@@ -60,6 +73,73 @@ def agg_kernel_bytes(N, E2, R2, D):
     return E2 * (4 * D + 16) + 2 * (N + 1) * 4 + 4 * N * D + 4 * (R2 + 1) * D + 4 * N * 3 * D
 
 
+def split_mfma_flops(N, D, O):
+    """MFMA flops the fused kernel actually issues per layer: six bf16 products over K padded to 32-wide k-blocks per
+    128-column chunk and O padded to 16-wide column tiles, 80-row tiles."""
+    kblocks, left = 0, D
+    while left > 0:
+        w = min(left, 128)
+        kblocks += (w + 31) // 32
+        left -= w
+    rows = (N + 79) // 80 * 80
+    return 6 * 2.0 * rows * (3 * kblocks * 32) * ((O + 15) // 16 * 16)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child of THIS process
+    (which has not touched the GPU: torch.cuda is never initialised here) and relay its output and exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, cwd=os.getcwd()).returncode
+
+
+def make_model(pkg, shape, dev, layers, seed, zipf, D=100, O=200):
+    N, R, E = shape['N'], shape['R'], shape['E']
+    params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=10,
+                                   k_h=20, num_filter=200, kernel_size=7, bias=False, lbl_smooth=0.1,
+                                   gcn_layers=layers, cache_encoder=False, device=dev)
+    edge_index, edge_attr = synth_graph(shape, seed=seed, zipf=zipf)
+    graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
+    graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
+    graph.to(dev)
+    torch.manual_seed(0)
+    model = pkg.MGCN(N, R, E, params)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():                                   # non-trivial BN statistics
+        for layer in [model.conv1] + list(model.conv1_extra):
+            layer.ent_bn.running_mean.copy_(torch.randn(O, generator=g) * 0.05)
+            layer.ent_bn.running_var.copy_(torch.rand(O, generator=g) * 0.5 + 0.05)
+    model.to(dev).eval()
+    return model, graph, params, edge_index, edge_attr
+
+
+def timed_steps(model, graph, steps, warmup, barrier, ramp_s=0.4):
+    """W untimed warm-up steps, then exactly K timed ones between two barriers. Before the warm-up the same step runs
+    untimed for `ramp_s` seconds: a fresh process otherwise measures the clock ramp and first-touch page faults of a
+    0.2 ms step instead of its steady state (--steps 20 --warmup 5 read 16 % slower than --steps 200)."""
+    def step():
+        with torch.no_grad():
+            return model.encode(graph)
+
+    t_end = time.perf_counter() + ramp_s
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -70,14 +150,16 @@ def main():
     ap.add_argument('--zipf', type=float, default=0.0, help='tail endpoints ~ Zipf(a) instead of uniform (hub-heavy profile)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
+    ap.add_argument('--no-fb', action='store_true', help='skip the FB15k-237-shape sub-objects (configs[2], configs[3])')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))                         # nothing above has initialised the GPU in this process
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
     # one rank per GPU; the modulo only matters when a multi-rank run is REHEARSED on a box with fewer GPUs
@@ -92,48 +174,20 @@ def main():
             dist.init_process_group(backend, device_id=dev)
         else:
             dist.init_process_group(backend)
-
-    pkg = importlib.import_module('kgc-gcn_amd')
-    shape = SHAPES[args.shape]
-    N, R, E = shape['N'], shape['R'], shape['E']
-    D, O = 100, 200
-    params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=10,
-                                   k_h=20, num_filter=200, kernel_size=7, bias=False, lbl_smooth=0.1,
-                                   gcn_layers=args.layers, cache_encoder=False, device=dev)
-
-    # every rank works on its own graph of the same shape (seed = rank): per-GPU work fixed -> weak scaling
-    edge_index, edge_attr = synth_graph(shape, seed=rank, zipf=args.zipf)
-    graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
-    graph.entity = torch.arange(N)
-    graph.num_nodes = N
-    graph.edge_norm = None
-    graph.to(dev)
-    torch.manual_seed(0)
-    model = pkg.MGCN(N, R, E, params)
-    g = torch.Generator().manual_seed(1)
-    with torch.no_grad():                                   # non-trivial BN statistics
-        for layer in [model.conv1] + list(model.conv1_extra):
-            layer.ent_bn.running_mean.copy_(torch.randn(O, generator=g) * 0.05)
-            layer.ent_bn.running_var.copy_(torch.rand(O, generator=g) * 0.5 + 0.05)
-    model.to(dev).eval()
-
-    def step():
-        with torch.no_grad():
-            return model.encode(graph)
+        assert dist.get_world_size() == world
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    pkg = importlib.import_module('kgc-gcn_amd')
+    shape = SHAPES[args.shape]
+    N, R, E = shape['N'], shape['R'], shape['E']
+    D, O = 100, 200
+    # every rank works on its own graph of the same shape (seed = rank): per-GPU work fixed -> weak scaling
+    model, graph, params, edge_index, edge_attr = make_model(pkg, shape, dev, args.layers, rank, args.zipf)
+    elapsed = timed_steps(model, graph, args.steps, args.warmup, barrier)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,31 +198,38 @@ def main():
     result = {
         'metric': 'aggregated_edges_per_sec', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (dense step as six bf16-split MFMA products, f32 accumulation: f32-faithful)', 'data': 'synthetic',
         'config': {'workload': '%s-shape synthetic graph (N=%d, R=%d, E=%d%s), %d-layer M-GCN encoder %s, full-graph '
                                'forward, eval mode' % (args.shape, N, R, E, ', Zipf(%.2f) tails' % args.zipf if args.zipf else '',
-                                                       args.layers,
-                                                       '->'.join(map(str, [D] + [O] * args.layers))),
+                                                       args.layers, '->'.join(map(str, [D] + [O] * args.layers))),
                    'edges_per_step_per_gpu': edges_per_step,
+                   'n_ranks_seen': dist.get_world_size() if dist is not None else 1,
                    'parallelism': 'one graph of this shape per GPU x%d, no data-path collective in the encoder step; '
                                   'the RCCL exchange of the sharded scoring pass is timed in "eval"' % world},
     }
 
     if rank == 0:
-        result.update(kernel_breakdown(pkg, model, graph, args, N, R, E, D, O))
+        result.update(kernel_breakdown(pkg, model, graph, args.steps, shape, args.shape, args.layers, D, O))
     if not args.no_eval:                                    # every rank takes part (collectives when W > 1)
         if rank != 0:                                       # the sharded pass needs ONE graph on all ranks: rank 0's
-            edge_index, edge_attr = synth_graph(shape, seed=0, zipf=args.zipf)
-            graph = pkg.Graph(edge_index=edge_index, edge_attr=edge_attr)
-            graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
-            graph.to(dev)                                   # (the per-edge tables are re-laid out for it on first use)
+            del model, graph
+            model, graph, params, edge_index, edge_attr = make_model(pkg, shape, dev, args.layers, 0, args.zipf)
         ev = eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank)
         if rank == 0:
             result['eval'] = ev
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O)
-            result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args.shape, args.layers, N, R, E, D, O, 20.0)
+        result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+
+    if not args.no_fb and args.shape == 'wn18rr':
+        del model, graph
+        torch.cuda.empty_cache()
+        fb = fb_sections(pkg, args, dev, world, rank, dist, barrier, D, O)
+        if rank == 0:
+            result['fb15k237'] = fb['step']
+            if 'eval' in fb:
+                result.setdefault('eval', {})['fb15k237'] = fb['eval']
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -177,43 +238,136 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
+def fb_sections(pkg, args, dev, world, rank, dist, barrier, D, O):
+    """BASELINE configs[2] (the encoder step on the FB15k-237 shape, hub-heavy Zipf(1.1) tails: "denser graph,
+    HBM-bound gather") and configs[3] (its full evaluation with the entity table sharded over the ranks)."""
+    shape = SHAPES['fb15k237']
+    N, R, E = shape['N'], shape['R'], shape['E']
+    zipf = 1.1
+    model, graph, params, edge_index, edge_attr = make_model(pkg, shape, dev, args.layers, 0, zipf)
+    out = {}
+    steps = max(args.steps, 20)
+    elapsed = timed_steps(model, graph, steps, args.warmup, barrier, ramp_s=0.2)
+    if rank == 0:
+        eps = args.layers * (2 * E + N)
+        step = {'workload': 'fb15k237-shape synthetic graph (N=%d, R=%d, E=%d, Zipf(%.1f) tails, hubs split), %d-layer '
+                            'encoder %s' % (N, R, E, zipf, args.layers, '->'.join(map(str, [D] + [O] * args.layers))),
+                'value': eps * steps / elapsed, 'unit': 'edges/s (this rank)', 'ms_per_step': 1e3 * elapsed / steps, 'steps': steps}
+        step.update(kernel_breakdown(pkg, model, graph, steps, shape, 'fb15k237', args.layers, D, O))
+        if not args.no_cpu_baseline and world == 1:
+            step['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, 'fb15k237', args.layers, N, R, E, D, O, 8.0,
+                                                with_eval=False)
+            step['gpu_over_cpu'] = step['value'] / step['cpu_baseline']['value']
+        out['step'] = step
+    else:
+        out['step'] = None
+    if not args.no_eval:
+        out['eval'] = fb_eval(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank, dist)
+    return out
+
+
+def fb_eval(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank, dist):
+    """configs[3]: 2 x 20 466 queries in blocks of 128 against 14 541 entities; entity rows sharded over the W ranks
+    (dist.evaluate_sharded: one all-gather of query embeddings / keys / objects, all-reduce of targets and int64 counts),
+    with the encoder replicated and with it partitioned by destination (shard_encoder). `one_rank_*`: the same
+    evaluation by rank 0 alone in the same process (a one-rank group, no collectives) — the N = 1 time to divide by."""
+    N, R = shape['N'], shape['R']
+    n_eval = shape['n_eval']
+    rng = np.random.default_rng(7)
+    s, r, o = rng.integers(0, N, 2 * n_eval), rng.integers(0, 2 * R, 2 * n_eval), rng.integers(0, N, 2 * n_eval)
+    queries = torch.from_numpy(np.stack((s, r, o), axis=1))
+    ei, et = edge_index.numpy(), edge_attr[0].numpy()
+    half = len(et) // 2
+    fwd = r < R                                                # a query with relation id r + R asks for the subject of (o, r, s)
+    tri = np.concatenate([np.stack((ei[0][:half], et[:half], ei[1][:half]), axis=1),
+                          np.stack((np.where(fwd, s, o), np.where(fwd, r, r - R), np.where(fwd, o, s)), axis=1)]).astype(np.int64)
+    keys, ptr, tails = pkg._native.filter_index_build(torch.from_numpy(tri), R)   # both directions of every known triple
+    filt = pkg.dist.FilterIndex(keys, ptr, tails, 2 * R).to(dev)
+    params.cache_encoder = True
+    out = {'queries': 2 * n_eval, 'batch': 128, 'world': world}
+    solo = dist.new_group([0]) if dist is not None else None     # (every rank must take part in creating it)
+
+    def run(group, shard_encoder):
+        best, res = None, None
+        for _ in range(3):
+            model._enc_cache = None
+            if dist is not None and group is None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = pkg.dist.evaluate_sharded(model, graph, queries, filt, batch_size=128, group=group,
+                                            shard_encoder=shard_encoder)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        return best, res
+
+    for name, se in (('sharded_s', False), ('sharded_encoder_too_s', True)):
+        t, res = run(None, se)
+        if dist is not None:
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        out[name] = t
+        out[name.replace('_s', '_mrr')] = res['mrr']
+    if world > 1:
+        if rank == 0:
+            t1, res1 = run(solo, False)
+            out['one_rank_s'] = t1
+            out['one_rank_mrr'] = res1['mrr']
+            out['speedup_vs_one_rank'] = t1 / out['sharded_s']
+            # integer counts are summed exactly, so for the SAME query embeddings the sharded ranks are the one-rank ranks
+            # (tests/test_gpu_parity.py::test_evaluate_sharded_two_ranks_one_gpu); here each rank runs the stock-torch
+            # ConvE trunk on its own slice of the queries, whose last chunk has another size than the one-rank run's, and
+            # torch's f32 results depend on the batch size in the last bits: the MRRs agree to north_star's 1e-4, not bitwise
+            assert abs(res1['mrr'] - out['sharded_mrr']) <= 1e-4, (res1['mrr'], out['sharded_mrr'])
+        dist.barrier()
+    else:
+        out['one_rank_s'], out['one_rank_mrr'] = out['sharded_s'], out['sharded_mrr']
+    params.cache_encoder = False
+    model._enc_cache = None
+    return out
+
+
+def source_fingerprint():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'kgc-gcn_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_breakdown(pkg, model, graph, K, shape, shape_name, n_layers, D, O):
     """Per-launch device time of the step's kernels, measured IN SEQUENCE (the same launches, order and
     operands as model.encode, so caches hold what they hold in the real step) with HIP events recorded on the
-    launch stream between the kernels, over the same K steps."""
+    launch stream between the kernels, over K steps; each launch priced against both roofs."""
     nat = pkg._native
+    N, R, E = shape['N'], shape['R'], shape['E']
     csr = graph.csr(2 * R + 1)
+    dev = model.entity_embedding.device
     layers = [model.conv1] + list(model.conv1_extra)
     tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
-    K = args.steps
     fused = all(nat.fused_supported(l.in_channels, l.out_channels) for l in layers)
-    bufs = []
-    for layer in layers:
-        bufs.append((torch.empty((N, 3 * layer.in_channels), device=model.entity_embedding.device),
-                     torch.empty((N, O), device=model.entity_embedding.device), layer.derived_weights()))
-
-    rel_outs = [torch.empty((2 * R, O), device=model.entity_embedding.device) for _ in layers]
+    bufs = [(torch.empty((N, 3 * l.in_channels), device=dev), torch.empty((N, O), device=dev), l.derived_weights()) for l in layers]
+    rel_outs = [torch.empty((2 * R, O), device=dev) for _ in layers]
 
     def sequence(events):
         x, rel = model.entity_embedding, model.relation_embedding
         i = 0
-        for layer, table, (agg, out, (wcat, wpack)) in zip(layers, tables, bufs):
+        for li, (layer, table, (agg, out, (wcat, wpack))) in enumerate(zip(layers, tables, bufs)):
             bn = layer.ent_bn
             events[i].record(); i += 1
-            if fused:     # one launch: the layer + a few workgroups for the relation projection (model.py:107)
-                rel_next = rel_outs[len(rel_outs) - len(layers) + layers.index(layer)]
+            if fused:     # one launch: the layer and the relation projection (model.py:107)
                 nat.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table, True, layer.loop_edge.reshape(-1), wpack,
                                     O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
-                                    rels_weight=layer.rels_weight.detach(), rel_out=rel_next)
+                                    rels_weight=layer.rels_weight.detach(), rel_out=rel_outs[li])
                 events[i].record(); i += 1
                 events[i].record(); i += 1
-                rel = rel_next
-                x = out
+                rel, x = rel_outs[li], out
                 continue
-            else:
-                nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1))
-                events[i].record(); i += 1
-                nat.dense_bn_tanh_fwd(agg, wcat, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
+            nat.aggregate_fwd(csr, x, rel, table, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1))
+            events[i].record(); i += 1
+            nat.dense_bn_tanh_fwd(agg, wcat, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
             events[i].record(); i += 1
             rel = nat.matmul(rel, layer.rels_weight)
             x = out
@@ -221,7 +375,8 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
 
     nev = 3 * len(layers) + 1
     with torch.no_grad():
-        sequence([torch.cuda.Event(enable_timing=True) for _ in range(nev)])
+        for _ in range(10):
+            sequence([torch.cuda.Event(enable_timing=True) for _ in range(nev)])
         torch.cuda.synchronize()
         all_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nev)] for _ in range(K)]
         for ev in all_ev:
@@ -232,16 +387,18 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
         for j, kind in enumerate(('aggregate', 'dense', 'relproj')):
             idx = 3 * li + j
             times['%s_l%d' % (kind, li + 1)] = float(np.mean([ev[idx].elapsed_time(ev[idx + 1]) for ev in all_ev])) * 1e3
-    dims = [D] + [O] * (args.layers - 1)
+    dims = [D] + [O] * (n_layers - 1)
     kern = {}
     for li, d in enumerate(dims):
         fl = 2.0 * N * 3 * d * O
         lb = layer_bytes(N, 2 * E, 2 * R, d, O)
         ta, td = times['aggregate_l%d' % (li + 1)], times['dense_l%d' % (li + 1)]
         if fused:       # the first slot holds the one fused launch, the second is empty
+            sf = split_mfma_flops(N, d, O)
             kern['layer_fused_l%d' % (li + 1)] = {
                 'us': ta, 'algorithmic_bytes': lb, 'GBps': lb / ta / 1e3, 'hbm_frac': lb / ta / 1e3 / HBM_PEAK_GBS,
-                'algorithmic_flops': fl, 'TFLOPs': fl / ta / 1e6, 'mfma_f32_frac': fl / ta / 1e6 / MFMA_F32_PEAK_TFLOPS}
+                'algorithmic_flops': fl, 'TFLOPs': fl / ta / 1e6, 'mfma_f32_frac': fl / ta / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                'issued_bf16_flops': sf, 'mfma_bf16_frac': sf / ta / 1e6 / MFMA_BF16_PEAK_TFLOPS}
         else:
             ab = agg_kernel_bytes(N, 2 * E, 2 * R, d)
             kern['aggregate_l%d' % (li + 1)] = {'us': ta, 'algorithmic_bytes': ab, 'GBps': ab / ta / 1e3,
@@ -250,12 +407,10 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
                                             'mfma_f32_frac': fl / td / 1e6 / MFMA_F32_PEAK_TFLOPS}
             kern['layer%d' % (li + 1)] = {'us': ta + td, 'algorithmic_bytes': lb,
                                           'hbm_frac': lb / (ta + td) / 1e3 / HBM_PEAK_GBS}
-        if not fused:
             kern['relproj_l%d' % (li + 1)] = {'us': times['relproj_l%d' % (li + 1)]}
     if fused:
         # the HBM-bound part on its own: the aggregation launch of the unfused path (what training's forward and
-        # shapes outside the fused kernel run) on the same operands, the layers alternating as in a real step so
-        # that the caches hold what they would hold there
+        # shapes outside the fused kernel run) on the same operands, the layers alternating as in a real step
         with torch.no_grad():
             rels = [model.relation_embedding]
             for layer in layers[:-1]:
@@ -286,30 +441,38 @@ def kernel_breakdown(pkg, model, graph, args, N, R, E, D, O):
     dom = max(cand, key=lambda k: cand[k]['us'])
     k = kern[dom]
     if dom.startswith('layer_fused'):
-        # one launch, two roofs: report the binding one (higher fraction of its peak) and keep both in `kernels`
-        if k['mfma_f32_frac'] >= k['hbm_frac']:
-            roof = {'kernel': 'layer_fused_kernel (%s)' % dom, 'bound': 'mfma', 'achieved': k['TFLOPs'],
-                    'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k['mfma_f32_frac'], 'traffic': None,
-                    'hbm_frac_same_launch': k['hbm_frac']}
-        else:
-            roof = {'kernel': 'layer_fused_kernel (%s)' % dom, 'bound': 'hbm', 'achieved': k['GBps'],
-                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': k['hbm_frac'], 'traffic': None,
-                    'mfma_f32_frac_same_launch': k['mfma_f32_frac']}
+        # north_star's roof for this path: HBM (SURVEY §8d algorithmic bytes / launch time / 8 TB/s). The dense step rides
+        # in the same launch: its algorithmic flops against the exact-f32 MFMA peak (what round 1 paid) and the flops
+        # actually issued (six bf16 products) against the bf16 peak are reported beside it, for BOTH layers.
+        roof = {'kernel': 'layer_fused2_kernel (%s)' % dom, 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': k['hbm_frac'], 'traffic': None,
+                'per_layer': {n: {'us': v['us'], 'hbm_frac': v['hbm_frac'], 'mfma_f32_frac': v['mfma_f32_frac'],
+                                  'mfma_bf16_frac': v['mfma_bf16_frac']}
+                              for n, v in kern.items() if n.startswith('layer_fused')}}
     elif dom.startswith('aggregate'):
         roof = {'kernel': 'agg_fwd_kernel (%s)' % dom, 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': k['hbm_frac'], 'traffic': None}
     else:
         roof = {'kernel': 'tile_kernel<BN_TANH> (%s)' % dom, 'bound': 'mfma', 'achieved': k['TFLOPs'],
                 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': k['mfma_f32_frac'], 'traffic': None}
-    # HBM-side bytes of the same launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-    # MI355X_MICROARCH.md prescribes); collected offline with the profiler, committed under profiles/.
+    # HBM-side bytes of the same launch from the PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # in separate passes, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/. The file carries the
+    # fingerprint of the kernel sources it was measured on: a stale file is NOT quoted.
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')) as f:
-            traffic = json.load(f)['kernels']
-        if args.shape == 'wn18rr' and dom in traffic:
+        with open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')) as f:
+            tj = json.load(f)
+        traffic = tj.get(shape_name, {})
+        if tj.get('source_fingerprint') != source_fingerprint():
+            roof['traffic_note'] = 'profiles/r02_traffic.json was measured on other kernel sources (%s != %s): not quoted' % (
+                tj.get('source_fingerprint'), source_fingerprint())
+            print('bench.py: ' + roof['traffic_note'], file=sys.stderr)
+        elif dom in traffic:
             roof['traffic'] = traffic[dom]['traffic_bytes']
-    except (OSError, KeyError, ValueError):
-        pass
+            for n in roof.get('per_layer', {}):
+                if n in traffic:
+                    roof['per_layer'][n]['traffic'] = traffic[n]['traffic_bytes']
+    except (OSError, KeyError, ValueError) as err:
+        roof['traffic_note'] = 'no PMC traffic file: %s' % err
     return {'roofline': roof, 'kernels': kern}
 
 
@@ -320,7 +483,10 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
                         score+filter+count kernel per block of 128 queries, entity table row-sharded over the ranks
                         (RCCL exchange if W > 1); sharded_bits_oneshot_s = the same with each rank's queries in ONE block;
       fused_dense_s     (rank 0 only) HIP kernel fed by dense [B, N] label blocks already resident on the device;
-      reference_order_s (rank 0 only) what main.py:117-126 does: encoder per batch, [B, N] scores, double argsort."""
+      reference_order_s (rank 0 only) what main.py:117-126 does: encoder per batch, [B, N] scores, double argsort.
+    The sharded form runs the ConvE trunk (stock torch, out of scope) in chunks of 2048 queries, the other two in
+    batches of 128: its f32 query embeddings differ in the last bits, so its MRR may differ from theirs in the 5th
+    significant digit (tests/test_gpu_bench_shapes.py pins the cause); asserted here within north_star's 1e-4."""
     N, R = shape['N'], shape['R']
     n_eval = min(shape['n_eval'], 4096)
     rng = np.random.default_rng(7)
@@ -375,6 +541,8 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
                 torch.cuda.synchronize()
                 out[name] = time.perf_counter() - t0
             out[name.replace('_s', '_mrr')] = mrr
+        assert abs(out['sharded_bits_mrr'] - out['reference_order_mrr']) <= 1e-4, out
+        assert abs(out['fused_dense_mrr'] - out['reference_order_mrr']) <= 1e-4, out
     params.cache_encoder = False
     model._enc_cache = None
     return out
@@ -396,15 +564,16 @@ def host_cores():
     return int(os.environ.get('MGCN_CPU_THREADS', min(n, 16)))   # a 1-GPU box's CPU share is 16
 
 
-def cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O):
+def cpu_baseline(model, edge_index, edge_attr, shape_name, n_layers, N, R, E, D, O, budget_s, with_eval=True):
     """The oracle (CPU restatement in the reference's order of operations: per-edge weight multiply, identity
-    gathers, norms recomputed per call) on this box's host cores, same graph and parameters, bounded sample."""
+    gathers, norms recomputed per call) on this box's host cores, same graph and parameters, bounded sample; one
+    forward also on ONE thread (BASELINE.md §2's single-thread figure)."""
     oracle = importlib.import_module('oracle.mgcn_oracle')
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cores = host_cores()
     torch.set_num_threads(cores)
-    prefixes = ['conv1.'] + ['conv1_extra.%d.' % i for i in range(args.layers - 1)]
-    tables = ['edge_embeddings'] + ['edge_embeddings_extra.%d' % i for i in range(args.layers - 1)]
+    prefixes = ['conv1.'] + ['conv1_extra.%d.' % i for i in range(n_layers - 1)]
+    tables = ['edge_embeddings'] + ['edge_embeddings_extra.%d' % i for i in range(n_layers - 1)]
 
     def cpu_step():
         x, rel = sd['entity_embedding'].index_select(0, torch.arange(N)), sd['relation_embedding']
@@ -417,11 +586,22 @@ def cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O):
         cpu_step()
         times = []
         t_start = time.perf_counter()
-        while len(times) < 20 and (time.perf_counter() - t_start < 20.0 or len(times) < 3):
+        while len(times) < 20 and (time.perf_counter() - t_start < budget_s or len(times) < 3):
             t0 = time.perf_counter()
             cpu_step()
             times.append(time.perf_counter() - t0)
+        torch.set_num_threads(1)
+        t0 = time.perf_counter()
+        cpu_step()
+        one_thread = time.perf_counter() - t0
+        torch.set_num_threads(cores)
     best = min(times)
+    res = {'value': n_layers * (2 * E + N) / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+           'sample': '%d full-graph %d-layer forwards of the same workload (min of %d, %.1f ms each)'
+                     % (len(times), n_layers, len(times), best * 1e3),
+           'one_thread_edges_per_s': n_layers * (2 * E + N) / one_thread}
+    if not with_eval:
+        return res
     # the evaluation in the reference's order (main.py:117-126: encoder per batch, [B, N] scores, double argsort) on
     # two batches of 128 queries, extrapolated to the benchmark's 2 x n_eval queries
     hp = {'gcn_out_dim': O, 'k_w': 10, 'k_h': 20}
@@ -440,12 +620,11 @@ def cpu_baseline(model, edge_index, edge_attr, args, N, R, E, D, O):
             pred = oracle.score_all(x, all_ent, sd['conv2.bias'])
             oracle.filtered_rank(pred, torch.zeros_like(pred), obj)
         per_batch = (time.perf_counter() - t0) / 2
-    n_batches = -(-2 * min(SHAPES[args.shape]['n_eval'], 4096) // B)
-    return {'value': args.layers * (2 * E + N) / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d full-graph %d-layer forwards of the same workload (min of %d, %.1f ms each)'
-                      % (len(times), args.layers, len(times), best * 1e3),
-            'eval_reference_order_s': per_batch * n_batches,
-            'eval_sample': '2 batches of %d queries in the reference order (%.2f s each), x %d batches' % (B, per_batch, n_batches)}
+    n_batches = -(-2 * min(SHAPES[shape_name]['n_eval'], 4096) // B)
+    res['eval_reference_order_s'] = per_batch * n_batches
+    res['eval_sample'] = '2 batches of %d queries in the reference order (%.2f s each), x %d batches (extrapolated)' % (
+        B, per_batch, n_batches)
+    return res
 
 
 if __name__ == '__main__':

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "mgcn_common.h"
 
@@ -29,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int T2 = 512;
+constexpr int T2 = 1024;   // 8 MFMA waves + 8 gather waves: two of each per SIMD, 128 VGPRs per wave
 
 struct Args2 {
   const int32_t *rowptr;
@@ -112,20 +113,20 @@ __global__ __launch_bounds__(256) void pack2_kernel(const float *__restrict__ w,
 
 __device__ __forceinline__ float4 f4mul2(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-// LDS: [2 stage images][epilogue vectors 5 x 208 floats][relation table, when RELLDS]
-constexpr int EPI_FLOATS = 5 * 208;
+// LDS: [2 stage images][epilogue vectors 2 x 208 floats][relation table, when RELLDS]
+constexpr int EPI_FLOATS = 2 * 208;
 constexpr int REL_LDS_MAX_BYTES = 32 * 1024;
 
-template <int NT, int NRT, bool RELLDS>
-__global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
+template <int NT, int NRT, bool RELLDS, bool HUBS>
+__global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
   constexpr int BM = NRT * 16;
   constexpr int PIECE = 16 * BM * 16;   // bytes of one bf16 piece of a stage image: 16 chunk columns x BM rows x 16 B
   constexpr int BUF = 3 * PIECE;
-  constexpr int RPG = BM / 8;           // destinations per gather group
-  constexpr int UB = RELLDS ? 12 : 8;   // slots per gather batch: 24 row loads in flight per lane group either way
+  constexpr int RPG = BM / 16;          // destinations per gather group (16 groups of 32 lanes)
+  constexpr int UB = 4;                 // slots per gather batch (the role is bound by instruction issue, not by latency)
   constexpr int CH = 32 / UB * UB;      // slots served by one record chunk (lane i: slot cbase + i)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
-  float *epi = reinterpret_cast<float *>(lds2 + 2 * BUF);   // [cb | mean | inv | gamma | beta] x 208
+  float *epi = reinterpret_cast<float *>(lds2 + 2 * BUF);   // [scale | shift] x 208: the epilogue as one fma per value
   float *rel_lds = epi + EPI_FLOATS;                         // [rel_rows - 1][D] when RELLDS
 
   const int bid = int(blockIdx.x), nblk = int(gridDim.x);
@@ -136,25 +137,21 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
   const int my_tiles = (ntiles - bid + nblk - 1) / nblk;   // >= 1 (grid <= ntiles)
   const int nch = p.nch;
 
-  // once per workgroup: the epilogue's per-column vectors (model.py:103-106) and, when it fits, the relation table
-  for (int c = tid; c < 208; c += T2) {
-    const bool in = c < p.o;
-    epi[c] = (in && p.bias) ? p.bias[c] : 0.f;
-    epi[208 + c] = in ? p.bn_mean[c] : 0.f;
-    epi[416 + c] = in ? __builtin_amdgcn_rsqf(p.bn_var[c] + p.bn_eps) : 0.f;
-    epi[624 + c] = in ? p.bn_gamma[c] : 0.f;
-    epi[832 + c] = in ? p.bn_beta[c] : 0.f;
+#ifdef MGCN_DIAG
+  if (p.stamps && lane == 0 && (wave == 0 || wave == 8)) {
+    p.stamps[(int64_t(blockIdx.x) * 2 + (wave ? 1 : 0)) * 128 + 120] = __builtin_readcyclecounter();
+    p.stamps[(int64_t(blockIdx.x) * 2 + (wave ? 1 : 0)) * 128 + 121] = __builtin_amdgcn_s_memrealtime();
   }
-  if (RELLDS) {
-    const int n4 = ((p.rel_rows - 1) * p.d) >> 2;
-    for (int i = tid; i < n4; i += T2)
-      reinterpret_cast<float4 *>(rel_lds)[i] = reinterpret_cast<const float4 *>(p.rel)[i];
-  }
-  __syncthreads();
-
-  if (wave >= 4) {
+#endif
+  // The per-stage workgroup barrier orders LDS only: the waves' own LDS operations are drained (lgkmcnt), vector memory
+  // is NOT (__syncthreads() would add s_waitcnt vmcnt(0): every barrier would then wait for the weight prefetch just
+  // issued, the next records, and — after an epilogue — for 64 KB of output stores to be acknowledged).
+  auto stage_barrier = [] () __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  if (wave >= 8) {
     // ------------------------------------------------------------------------------------------ GATHER
-    const int gtid = tid - 256;
+    const int gtid = tid - 512;
     const int grp = gtid >> 5, lig = gtid & 31;
     const int glane0 = lane & 32;
     const int g_lo = grp * RPG, g_hi = g_lo + RPG;
@@ -173,52 +170,106 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
       *reinterpret_cast<uint2 *>(dst + PIECE) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
       *reinterpret_cast<uint2 *>(dst + 2 * PIECE) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
     };
-    // lane i of a group holds the row pointer of destination g_lo + i (i <= RPG) and the record of slot beg + i:
-    // both are fetched one (tile, mode) ahead, so a stage starts straight at its row loads.
+    // Edge stages: the tile's BM destinations are dealt to the 16 lane groups by WORK, not by count: group g takes the
+    // rows whose work prefix P(i) = slots before row i + c * i falls into [g, g + 1) * P(BM) / 16 (c = cost of an empty
+    // row, raised with the tile's slot count so that no group gets more than 31 rows). A stage ends when its slowest
+    // group ends: with 5 rows each the slowest of 16 groups carried ~1.6x the mean slots, by work ~1.15x. Every row's
+    // slots are still summed by ONE group in slot order, so sums do not depend on the partition.
+    // Per group, lane l holds the tile's row pointers l, l + 32, l + 64 (clamped to BM); both the pointers and the
+    // group's first slot records are fetched one (tile, mode) ahead, so a stage starts straight at its row loads.
+    struct RowPtrs { int a, b, c; };
     auto rp_of = [&](int it_, int mode_) {
-      int node = p.node0 + (bid + it_ * nblk) * BM + g_lo + (lig <= RPG ? lig : RPG);
-      node = node < p.node1 ? node : p.node1;
-      return p.rowptr[int64_t(mode_) * (p.n + 1) + node];
+      const int32_t *rp = p.rowptr + int64_t(mode_) * (p.n + 1);
+      const int row0 = p.node0 + (bid + it_ * nblk) * BM;
+      auto at = [&](int i) {
+        int node = row0 + (i < BM ? i : BM);
+        node = node < p.node1 ? node : p.node1;
+        return rp[node];
+      };
+      RowPtrs r;
+      r.a = at(lig); r.b = at(lig + 32); r.c = at(lig + 64);
+      return r;
+    };
+    auto rp_get = [&](const RowPtrs &r, int idx) {      // idx group-uniform, 0..BM: the tile's row pointer idx
+      const int from = glane0 + (idx & 31);
+      const int va = __shfl(r.a, from), vb = __shfl(r.b, from), vc = __shfl(r.c, from);
+      return idx < 32 ? va : (idx < 64 ? vb : vc);
+    };
+    struct Part { int lo, hi, rp; };                     // rows [lo, hi) of the tile; rp: lane l holds row pointer lo + min(l, hi - lo)
+    auto partition = [&](const RowPtrs &r) {
+      const int base = __shfl(r.a, glane0);
+      const int tot = rp_get(r, BM) - base;
+      const int c = 2 > (tot >> 8) + 1 ? 2 : (tot >> 8) + 1;
+      const int ptot = tot + c * BM;
+      const int thr_lo = (grp * ptot) >> 4, thr_hi = ((grp + 1) * ptot) >> 4;
+      int lo = 0, hi = 0;
+      const int vals[3] = {r.a, r.b, r.c};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lig + 32 * k;
+        const int pw = (vals[k] - base) + c * i;
+        const unsigned long long blo = __ballot(i < BM && pw < thr_lo), bhi = __ballot(i < BM && pw < thr_hi);
+        lo += __popc(uint32_t(blo >> glane0));
+        hi += __popc(uint32_t(bhi >> glane0));
+      }
+      Part q;
+      q.lo = lo; q.hi = hi;
+      const int idx = lo + (lig < hi - lo ? lig : hi - lo);
+      const int from = glane0 + (idx & 31);
+      const int va = __shfl(r.a, from), vb = __shfl(r.b, from), vc = __shfl(r.c, from);
+      q.rp = idx < 32 ? va : (idx < 64 ? vb : vc);
+      return q;
     };
     auto rec_chunk = [&](int cbeg, int end) {   // lane i: record of slot cbeg + i (clamped to the range's last slot)
       int4 r = make_int4(0, 0, 0, 0);
       if (end > cbeg) r = p.rec[(cbeg + lig < end) ? cbeg + lig : end - 1];
       return r;
     };
-    int currp = rp_of(0, 0);
-    int4 currec = rec_chunk(__shfl(currp, glane0), __shfl(currp, glane0 + RPG));
+    Part cur = partition(rp_of(0, 0));
+    int4 currec = rec_chunk(__shfl(cur.rp, glane0), __shfl(cur.rp, glane0 + (cur.hi - cur.lo)));
     int stage = 0;
     for (int it = 0; it < my_tiles; ++it) {
       const int r0 = p.node0 + (bid + it * nblk) * BM;
-      for (int mode = 0; mode < 3; ++mode) {
+      // stage order per tile: self loop, in-half, out-half. The first stage of the launch has nothing to overlap with:
+      // it is the cheap one (no slot records, no dependent loads), and the relation table / epilogue vectors the MFMA
+      // waves put into LDS meanwhile are published by that stage's barrier, before the first edge stage reads them.
+      for (int mi = 0; mi < 3; ++mi) {
+        const int mode = mi == 0 ? 2 : mi - 1;
         if (mode < 2) {
-          const int myrp = currp;
+          const int myrp = cur.rp, e_lo = cur.lo, e_hi = cur.hi, e_n = cur.hi - cur.lo;   // this group's rows [e_lo, e_hi)
           const int4 firstrec = currec;
           const int ee_sub_mode = p.ee_sub[mode];
           const bool has_next = mode == 0 || it + 1 < my_tiles;   // next (tile, mode) with records
-          int nrp = 0;
+          RowPtrs nrp = {0, 0, 0};
           if (has_next) nrp = rp_of(mode == 0 ? it : it + 1, mode == 0 ? 1 : 0);
+          Part nxt = {0, 0, 0};
           bool next_recs_issued = false;
           int4 nrec = make_int4(0, 0, 0, 0);
-          int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination g_lo + i
+          auto prefetch_next = [&]() __attribute__((always_inline)) {   // the next (tile, mode)'s partition and first records
+            if (has_next) {
+              nxt = partition(nrp);
+              nrec = rec_chunk(__shfl(nxt.rp, glane0), __shfl(nxt.rp, glane0 + (nxt.hi - nxt.lo)));
+            }
+          };
+          int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination e_lo + i
           {
-            const int node = r0 + g_lo + (lig <= RPG ? lig : RPG);
-            if (p.hubinfo && lig < RPG && node < p.node1) myhub = p.hubinfo[int64_t(mode) * p.n + node];
+            const int node = r0 + e_lo + lig;
+            if (HUBS && p.hubinfo && lig < e_n && node < p.node1) myhub = p.hubinfo[int64_t(mode) * p.n + node];
           }
-          const int beg = __shfl(myrp, glane0), end = MGCN_ABLATE(1) ? beg : __shfl(myrp, glane0 + RPG);
+          const int beg = __shfl(myrp, glane0), end = MGCN_ABLATE(1) ? beg : __shfl(myrp, glane0 + e_n);
           for (int chunk = 0; chunk < nch; ++chunk, ++stage) {
-            if (wave == 4) MGCN_STAMP(1, 2 * stage);
+            if (wave == 8) MGCN_STAMP(1, 2 * stage);
             unsigned char *img = lds2 + (stage & 1) * BUF;
             const int coff_ = chunk * 128 + lig * 4;
             const bool col_ok = coff_ < p.d;
             const int coff = col_ok ? coff_ : 0;   // lanes past the row width repeat columns 0-3 and store zeros
             const float *xb = p.x + coff, *relb = (RELLDS ? rel_lds : p.rel) + coff, *eeb = p.ee + coff;
             int4 myrec = firstrec;
-            int row = g_lo, nb = __shfl(myrp, glane0 + 1);
+            int row = e_lo, nb = __shfl(myrp, glane0 + 1);
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
             auto flush = [&]() __attribute__((always_inline)) {   // the run of destination `row` is complete (group-uniform)
-              if (p.hubinfo) {     // a hub's own run is empty: its folded total sits in the row of its first chunk
-                const int first = __shfl(myhub.x, glane0 + (row - g_lo)), cnt = __shfl(myhub.y, glane0 + (row - g_lo));
+              if (HUBS && p.hubinfo) {     // a hub's own run is empty: its folded total sits in the row of its first chunk
+                const int first = __shfl(myhub.x, glane0 + (row - e_lo)), cnt = __shfl(myhub.y, glane0 + (row - e_lo));
                 if (cnt > 0) {
                   const float4 ps = *reinterpret_cast<const float4 *>(p.partial + int64_t(first - p.chunk0) * p.d + coff);
                   sum = make_float4(sum.x + ps.x, sum.y + ps.y, sum.z + ps.z, sum.w + ps.w);
@@ -245,21 +296,22 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
               float4 xv[UB], rv[UB], ev[UB];
 #pragma unroll
               for (int u = 0; u < UB; ++u) {
+                if (MGCN_ABLATE(16)) rsrc[u] = 0;    // (diagnostics: every row load hits the same cached lines)
                 xv[u] = *reinterpret_cast<const float4 *>(xb + uint64_t(uint32_t(rsrc[u])) * ldx32);
                 if (!RELLDS) rv[u] = *reinterpret_cast<const float4 *>(relb + uint64_t(uint32_t(rtyp[u])) * d32);
-                const uint32_t erow = uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
+                const uint32_t erow = MGCN_ABLATE(16) ? 0u : uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
                 ev[u] = *reinterpret_cast<const float4 *>(eeb + uint64_t(erow) * d32);
               }
-              if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s first records
+              if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s partition and records
                 next_recs_issued = true;
-                if (has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + RPG));
+                prefetch_next();
               }
 #pragma unroll
               for (int u = 0; u < UB; ++u) {
                 if (s + u < end) {
                   while (s + u >= nb) {
                     flush();
-                    nb = __shfl(myrp, glane0 + (row - g_lo) + 1);
+                    nb = __shfl(myrp, glane0 + (row - e_lo) + 1);
                   }
                   const float4 rr = RELLDS ? *reinterpret_cast<const float4 *>(relb + uint32_t(rtyp[u]) * d32) : rv[u];
                   const float4 m = f4mul2(f4mul2(xv[u], rr), ev[u]);
@@ -270,17 +322,17 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
             }
             if (!next_recs_issued) {
               next_recs_issued = true;
-              if (has_next) nrec = rec_chunk(__shfl(nrp, glane0), __shfl(nrp, glane0 + RPG));
+              prefetch_next();
             }
-            while (row < g_hi) flush();  // last run, then zero rows for destinations without slots
-            if (wave == 4) MGCN_STAMP(1, 2 * stage + 1);
-            __syncthreads();             // end of stage: image stage & 1 is complete
+            while (row < e_hi) flush();  // last run, then zero rows for destinations without slots
+            if (wave == 8) MGCN_STAMP(1, 2 * stage + 1);
+            stage_barrier();             // end of stage: image stage & 1 is complete
           }
-          currp = nrp;
+          cur = nxt;
           currec = nrec;
         } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101
           for (int chunk = 0; chunk < nch; ++chunk, ++stage) {
-            if (wave == 4) MGCN_STAMP(1, 2 * stage);
+            if (wave == 8) MGCN_STAMP(1, 2 * stage);
             unsigned char *img = lds2 + (stage & 1) * BUF;
             const int coff_ = chunk * 128 + lig * 4;
             const bool col_ok = coff_ < p.d;
@@ -295,30 +347,79 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
             }
 #pragma unroll
             for (int i = 0; i < RPG; ++i) write_row(img, g_lo + i, f4mul2(f4mul2(xs[i], lr), le), col_ok);
-            if (wave == 4) MGCN_STAMP(1, 2 * stage + 1);
-            __syncthreads();
+            if (wave == 8) MGCN_STAMP(1, 2 * stage + 1);
+            stage_barrier();
           }
         }
       }
     }
+    // all_rel = rel @ rels_weight (model.py:107), by the gather waves once their last stage is in LDS (the MFMA waves
+    // still have that stage and the last epilogue to go). One item = one relation row x 16 columns per wave: the four
+    // 16-lane groups run the four K quarters of small_matmul_kernel's arithmetic (sequential fmaf chains), the partial
+    // sums are added in quarter order — values bit-identical to the separate launch, one load round trip per 32 k.
+    if (p.rel_out) {
+      const int rows = p.rel_rows - 1, k = p.d, n = p.o;
+      const int ncg = (n + 15) / 16, items = rows * ncg;
+      const int kper = (k + 3) / 4;
+      const int qd = lane >> 4;
+      const int k0 = qd * kper, k1 = (k0 + kper < k) ? k0 + kper : k;
+      for (int item = (wave - 8) * nblk + bid; item < items; item += nblk * 8) {
+        const int row = item / ncg, col = (item - row * ncg) * 16 + (lane & 15);
+        const bool ok = col < n;
+        const float *ap = p.rel + int64_t(row) * k;
+        const float *bp = p.rw + (ok ? col : 0);
+        float a = 0.f;
+        constexpr int UR = 32;
+        for (int i0 = 0; i0 < kper; i0 += UR) {
+          float av[UR], bv[UR];
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int kk = k0 + i0 + u;
+            const int kc = (i0 + u < kper && kk < k1) ? kk : 0;
+            av[u] = ap[kc];
+            bv[u] = bp[int64_t(kc) * n];
+          }
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int kk = k0 + i0 + u;
+            if (i0 + u < kper && kk < k1) a = fmaf(av[u], bv[u], a);
+          }
+        }
+        const float q1 = __shfl(a, (lane & 15) + 16), q2 = __shfl(a, (lane & 15) + 32), q3 = __shfl(a, (lane & 15) + 48);
+        if (qd == 0 && ok) p.rel_out[int64_t(row) * n + col] = ((a + q1) + q2) + q3;
+      }
+    }
+#ifdef MGCN_DIAG
+    if (p.stamps && lane == 0 && wave == 8) {
+      p.stamps[(int64_t(blockIdx.x) * 2 + 1) * 128 + 122] = __builtin_readcyclecounter();
+      p.stamps[(int64_t(blockIdx.x) * 2 + 1) * 128 + 123] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
   } else {
     // ------------------------------------------------------------------------------------------ MULTIPLY
-    constexpr int Q = NT / 4, R = NT % 4;
+    auto multiply = [&](auto Hc) __attribute__((always_inline)) {
+    constexpr int H = decltype(Hc)::value;
+    // Column group sg = wave & 3 (the SIMD) owns NT/4 column tiles; its two waves split them: half H = 0 takes the
+    // first ceil, half H = 1 the rest plus the group's share of the NT % 4 left-over column tiles, dealt as single
+    // (column tile, row tile) units. Two MFMA waves per SIMD: one's fragment waits are the other's issue slots.
+    constexpr int QALL = NT / 4, R = NT % 4;
+    constexpr int QA = (QALL + 1) / 2;
+    constexpr int Q = H == 0 ? QA : QALL - QA;       // this wave's whole column tiles
     constexpr int QF = Q > 0 ? Q : 1;
-    constexpr int NX = R * NRT;                      // single (column tile, row tile) units shared out round-robin
+    constexpr int NX = H == 1 ? R * NRT : 0;         // single units shared out round-robin over the four H = 1 waves
     constexpr int XE = (NX + 3) / 4;                 // ... at most XE per wave
     constexpr int XF = XE > 0 ? XE : 1;
     constexpr int XW = (R == 1) ? 1 : XF;            // weight fragments for them (R == 1: all in one column tile)
-    const int w = wave;
+    const int w = wave & 3;
     const int r = lane & 15, gq = lane >> 4;
-    const int ct0 = w * Q;
+    const int ct0 = w * QALL + (H == 0 ? 0 : QA);
     int xct[XF], xrt[XF];
     bool xok[XF];
 #pragma unroll
     for (int j = 0; j < XF; ++j) {
       const int e = 4 * j + w;
       xok[j] = XE > 0 && e < NX;
-      xct[j] = xok[j] ? 4 * Q + e / NRT : 0;
+      xct[j] = xok[j] ? 4 * QALL + e / NRT : 0;
       xrt[j] = xok[j] ? e % NRT : -1;
     }
     const int G = p.G;
@@ -353,13 +454,10 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
       for (int j = 0; j < XF; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     // lane holds out[row = 16 rt + r][16 ct + 4 gq .. + 3] (operands swapped: W is the MFMA's A operand)
-    auto store_unit = [&](f32x4 a, int prow, int col, const float4 &mean, const float4 &inv, const float4 &gam,
-                          const float4 &bet, const float4 &cb) {
+    auto store_unit = [&](f32x4 a, int prow, int col, const float4 &sc, const float4 &sh) {
       if (prow < nrows) {
-        constexpr float third = 1.0f / 3.0f;   // (sum of the three modes) / 3, model.py:103, as a multiplication (<= 1 ulp)
-        float4 v = make_float4(a[0] * third + cb.x, a[1] * third + cb.y, a[2] * third + cb.z, a[3] * third + cb.w);
-        v = make_float4(tanh2_((v.x - mean.x) * inv.x * gam.x + bet.x), tanh2_((v.y - mean.y) * inv.y * gam.y + bet.y),
-                        tanh2_((v.z - mean.z) * inv.z * gam.z + bet.z), tanh2_((v.w - mean.w) * inv.w * gam.w + bet.w));
+        const float4 v = make_float4(tanh2_(fmaf(a[0], sc.x, sh.x)), tanh2_(fmaf(a[1], sc.y, sh.y)),
+                                     tanh2_(fmaf(a[2], sc.z, sh.z)), tanh2_(fmaf(a[3], sc.w, sh.w)));
         *reinterpret_cast<float4 *>(p.out + int64_t(prow) * p.ldo + col) = v;
       }
     };
@@ -367,30 +465,20 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
       const int prow0 = tile * BM + r;
       auto column_tile = [&](int ct, auto &&body) {
         const int col = ct * 16 + 4 * gq;
-        if (col < p.o) {
-          const float4 cb = *reinterpret_cast<const float4 *>(epi + col);
-          const float4 mean = *reinterpret_cast<const float4 *>(epi + 208 + col);
-          const float4 inv = *reinterpret_cast<const float4 *>(epi + 416 + col);
-          const float4 gam = *reinterpret_cast<const float4 *>(epi + 624 + col);
-          const float4 bet = *reinterpret_cast<const float4 *>(epi + 832 + col);
-          body(col, mean, inv, gam, bet, cb);
-        }
+        if (col < p.o) body(col, *reinterpret_cast<const float4 *>(epi + col), *reinterpret_cast<const float4 *>(epi + 208 + col));
       };
 #pragma unroll
       for (int t = 0; t < Q; ++t) {
-        column_tile(ct0 + t, [&](int col, const float4 &mean, const float4 &inv, const float4 &gam, const float4 &bet,
-                                 const float4 &cb) {
+        column_tile(ct0 + t, [&](int col, const float4 &sc, const float4 &sh) {
 #pragma unroll
-          for (int rt = 0; rt < NRT; ++rt) store_unit(acc[rt][t], prow0 + rt * 16, col, mean, inv, gam, bet, cb);
+          for (int rt = 0; rt < NRT; ++rt) store_unit(acc[rt][t], prow0 + rt * 16, col, sc, sh);
         });
       }
       if (XE > 0) {
 #pragma unroll
         for (int j = 0; j < XF; ++j) {
-          if (xok[j]) {
-            column_tile(xct[j], [&](int col, const float4 &mean, const float4 &inv, const float4 &gam, const float4 &bet,
-                                    const float4 &cb) { store_unit(accx[j], prow0 + xrt[j] * 16, col, mean, inv, gam, bet, cb); });
-          }
+          if (xok[j])
+            column_tile(xct[j], [&](int col, const float4 &sc, const float4 &sh) { store_unit(accx[j], prow0 + xrt[j] * 16, col, sc, sh); });
         }
       }
     };
@@ -400,6 +488,7 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
     // spread the weight reads over the L2 channels: no gain, and it breaks that bit-identity.)
     auto rotated = [&](int kb_, int) { return kb_; };
     int kb = 0, chunk = 0, stage = 0;
+    bool barrier_done = false;
     int nkb_ = 0, nchunk = 0, nmode = 0;          // the k-block after the current one: (mode, chunk, ordinal)
     auto advance_next = [&]() {
       const int n = (nchunk == nch - 1) ? p.nkb_last : 4;
@@ -411,57 +500,38 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
         }
       }
     };
-    auto gindex = [&]() { return nmode * p.kbm + 4 * nchunk + rotated(nkb_, nchunk); };
+    auto gindex = [&]() {   // (packed weights are mode-major in the order in-half, out-half, self loop; stages run loop, in, out)
+      const int mode_ = nmode == 0 ? 2 : nmode - 1;
+      return mode_ * p.kbm + 4 * nchunk + rotated(nkb_, nchunk);
+    };
     wload(wq0, wx0, gindex());
     advance_next();
-    // all_rel = rel @ rels_weight (model.py:107) while the first stage is being gathered: one item = one relation
-    // row x 64 columns per wave, with small_matmul_kernel's arithmetic (K in quarters, sequential fmaf chains,
-    // the four partial sums added in order), so the values are bit-identical to the separate launch.
-    if (p.rel_out) {
-      const int rows = p.rel_rows - 1, k = p.d, n = p.o;
-      const int ngrp = (n + 63) / 64, items = rows * ngrp;
-      const int kper = (k + 3) / 4;
-      // items dealt wave-major (wave 0 of every workgroup first): at most one item per workgroup for up to 4 * grid items
-      for (int item = w * nblk + bid; item < items; item += nblk * 4) {
-        const int row = item / ngrp, col = (item - row * ngrp) * 64 + lane;
-        const bool ok = col < n;
-        const float *ap = p.rel + int64_t(row) * k;
-        const float *bp = p.rw + (ok ? col : 0);
-        float a4[4] = {0.f, 0.f, 0.f, 0.f};
-        constexpr int UR = 8;                    // 4 x 8 x 2 loads in flight, then the fmaf chains (K order kept per quarter)
-        for (int i0 = 0; i0 < kper; i0 += UR) {
-          float av[4][UR], bv[4][UR];
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const int k1 = (qd * kper + kper < k) ? qd * kper + kper : k;
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-              const int kk = qd * kper + i0 + u;
-              const int kc = (i0 + u < kper && kk < k1) ? kk : 0;
-              av[qd][u] = ap[kc];
-              bv[qd][u] = bp[int64_t(kc) * n];
-            }
-          }
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const int k1 = (qd * kper + kper < k) ? qd * kper + kper : k;
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-              const int kk = qd * kper + i0 + u;
-              if (i0 + u < kper && kk < k1) a4[qd] = fmaf(av[qd][u], bv[qd][u], a4[qd]);
-            }
-          }
-        }
-        if (ok) p.rel_out[int64_t(row) * n + col] = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+    // once per workgroup, by the MFMA waves while the first stage is gathered: the epilogue's per-column vectors
+    // (model.py:103-106 as one fma: tanh(acc * scale + shift)) and, when it fits, the relation table. Both are published
+    // to the gather waves by the first stage barrier.
+    if (H == 0) {
+      const int t8 = (wave & 3) * 64 + lane;
+      if (t8 < 208) {
+        const int c = t8;
+        const bool in = c < p.o;
+        const float inv = in ? __builtin_amdgcn_rsqf(p.bn_var[c] + p.bn_eps) * p.bn_gamma[c] : 0.f;
+        constexpr float third = 1.0f / 3.0f;   // (sum of the three modes) / 3, model.py:103, as a multiplication (<= 1 ulp)
+        epi[c] = inv * third;
+        epi[208 + c] = in ? ((p.bias ? p.bias[c] : 0.f) - p.bn_mean[c]) * inv + p.bn_beta[c] : 0.f;
       }
     }
-
+    if (RELLDS) {
+      const int n4 = ((p.rel_rows - 1) * p.d) >> 2;
+      for (int i = wave * 64 + lane; i < n4; i += 512)
+        reinterpret_cast<float4 *>(rel_lds)[i] = reinterpret_cast<const float4 *>(p.rel)[i];
+    }
     auto kblock = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], u32x4 (&nq)[QF][3], u32x4 (&nx)[XW][3]) {
       wload(nq, nx, gindex());           // the k-block after this one (wraps into the next tile: same weights)
       advance_next();
       const int nkb_c = (chunk == nch - 1) ? p.nkb_last : 4;
       if (kb == 0) {
-        __syncthreads();                // the stage's image is complete
+        if (!barrier_done) stage_barrier();   // the stage's image is complete
+        barrier_done = false;
         if (wave == 0) MGCN_STAMP(0, 2 * stage);
       }
       const int qc = 4 * rotated(kb, chunk) + gq;
@@ -513,24 +583,41 @@ __global__ __launch_bounds__(T2, 2) void layer_fused2_kernel(Args2 p) {
         kblock(wq1, wx1, wq2, wx2);
         kblock(wq2, wx2, wq0, wx0);
       }
+      // the next tile's first barrier comes BEFORE this tile's epilogue: the images are not read any more, so the gather
+      // waves go on with their next stage while these waves finish the rows (the accumulators are theirs alone)
+      if (it + 1 < my_tiles) {
+        stage_barrier();
+        barrier_done = true;
+      }
+      if (wave == 0) MGCN_STAMP(0, 100 + 2 * it);
       if (!MGCN_ABLATE(4)) epilogue(bid + it * nblk);
+      if (wave == 0) MGCN_STAMP(0, 101 + 2 * it);
     }
+#ifdef MGCN_DIAG
+    if (p.stamps && lane == 0 && wave == 0) {
+      p.stamps[int64_t(blockIdx.x) * 2 * 128 + 122] = __builtin_readcyclecounter();
+      p.stamps[int64_t(blockIdx.x) * 2 * 128 + 123] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    };
+    if (wave < 4) multiply(std::integral_constant<int, 0>{});
+    else multiply(std::integral_constant<int, 1>{});
   }
 }
 
-template <int NT, int NRT, bool RELLDS>
+template <int NT, int NRT, bool RELLDS, bool HUBS>
 int launch2(const Args2 &p, int grid, hipStream_t st) {
   constexpr size_t lds_bytes = size_t(2) * 3 * 16 * (NRT * 16) * 16 + EPI_FLOATS * 4 + (RELLDS ? REL_LDS_MAX_BYTES : 0);
   static bool attr_set[64] = {};   // per device, set once (the attribute is sticky): not re-done per call
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_fused2_kernel<NT, NRT, RELLDS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_fused2_kernel<NT, NRT, RELLDS, HUBS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)) != hipSuccess)
       return mgcn::fail(MGCN_ELAUNCH, "layer_fused2: cannot reserve %zu bytes of LDS", lds_bytes);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((layer_fused2_kernel<NT, NRT, RELLDS>), dim3(unsigned(grid)), dim3(T2), lds_bytes, st, p);
+  hipLaunchKernelGGL((layer_fused2_kernel<NT, NRT, RELLDS, HUBS>), dim3(unsigned(grid)), dim3(T2), lds_bytes, st, p);
   MGCN_CHECK_LAUNCH("layer_fused2_kernel");
   return MGCN_OK;
 }
@@ -625,15 +712,15 @@ int fused2_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the relation table rides in LDS when it fits beside the stage images (a third of the gather's row loads)
   const bool rel_lds = rel_dev && size_t(num_rel_rows - 1) * dim_in * 4 <= size_t(REL_LDS_MAX_BYTES);
-  switch (pick_nt2(dim_out) * 2 + (rel_lds ? 1 : 0)) {
-    case 4: return launch2<2, NRT, false>(p, grid, st);
-    case 5: return launch2<2, NRT, true>(p, grid, st);
-    case 8: return launch2<4, NRT, false>(p, grid, st);
-    case 9: return launch2<4, NRT, true>(p, grid, st);
-    case 16: return launch2<8, NRT, false>(p, grid, st);
-    case 17: return launch2<8, NRT, true>(p, grid, st);
-    case 26: return launch2<13, NRT, false>(p, grid, st);
-    default: return launch2<13, NRT, true>(p, grid, st);
+  // NT = 13 (the 200-wide layers) has all four variants; narrower outputs take the general one
+  const bool hubs = hubinfo_dev != nullptr;
+  switch (pick_nt2(dim_out)) {
+    case 2: return launch2<2, NRT, false, true>(p, grid, st);
+    case 4: return launch2<4, NRT, false, true>(p, grid, st);
+    case 8: return launch2<8, NRT, false, true>(p, grid, st);
+    default:
+      if (rel_lds) return hubs ? launch2<13, NRT, true, true>(p, grid, st) : launch2<13, NRT, true, false>(p, grid, st);
+      return hubs ? launch2<13, NRT, false, true>(p, grid, st) : launch2<13, NRT, false, false>(p, grid, st);
   }
 }
 

@@ -54,10 +54,27 @@ def main():
         for s in range(nst):
             g0, g1, m0, m1 = st[b, 1, 2 * s], st[b, 1, 2 * s + 1], st[b, 0, 2 * s], st[b, 0, 2 * s + 1]
             print('  stage %2d  gather start %7d work %6d | multiply start %7d work %6d' % (s, g0 - t0, g1 - g0, m0 - t0, m1 - m0))
+    b = 100
+    base = st[b, 0, 120]
+    ev = [('entry', st[b, 0, 120])] + [('m%d start' % i, st[b, 0, 2 * i]) for i in range(nst)] + \
+         [('m%d end' % i, st[b, 0, 2 * i + 1]) for i in range(nst)] + [('g%d start' % i, st[b, 1, 2 * i]) for i in range(nst)] + \
+         [('g%d end' % i, st[b, 1, 2 * i + 1]) for i in range(nst)] + [('epi0 start', st[b, 0, 100]), ('epi0 end', st[b, 0, 101]),
+          ('epi1 start', st[b, 0, 102]), ('epi1 end', st[b, 0, 103]), ('m exit', st[b, 0, 122]), ('g exit', st[b, 1, 122])]
+    print('block 100 events (cycles since entry):', ', '.join('%s %d' % (n, t - base) for n, t in sorted(ev, key=lambda e: e[1])))
     gw = (st[:, 1, 1:2 * nst:2] - st[:, 1, 0:2 * nst:2])
     mw = (st[:, 0, 1:2 * nst:2] - st[:, 0, 0:2 * nst:2])
     print('median gather work per stage :', np.median(gw, axis=0).astype(int).tolist())
     print('median multiply work per stage:', np.median(mw, axis=0).astype(int).tolist())
+    for role, name in ((0, 'multiply'), (1, 'gather')):
+        dc = (st[:, role, 122] - st[:, role, 120]).astype(float)
+        dr = (st[:, role, 123] - st[:, role, 121]).astype(float) / 100.0      # us (100 MHz)
+        print('%s role: lifetime median %.1f us (max %.1f), %d cycles => clock %.2f GHz; first stage starts %d cycles after entry'
+              % (name, np.median(dr), dr.max(), np.median(dc), np.median(dc / dr) / 1e3, np.median(st[:, role, 0] - st[:, role, 120])))
+    print('epilogue of tile 0 / 1 (cycles, median):', int(np.median(st[:, 0, 101] - st[:, 0, 100])), int(np.median(st[:, 0, 103] - st[:, 0, 102])),
+          '; last stage end -> epilogue start:', int(np.median(st[:, 0, 102] - st[:, 0, 2 * nst - 1])),
+          '; tile-0 epilogue end -> next stage start:', int(np.median(st[:, 0, 2 * (nst // 2)] - st[:, 0, 101])))
+    r0, r1 = st[:, :, 121].min(), st[:, :, 123].max()
+    print('all workgroups: first entry to last exit %.1f us; entry spread %.1f us' % ((r1 - r0) / 100.0, (st[:, 0, 121].max() - r0) / 100.0))
     print('median end (cycles): gather %d multiply %d' % (np.median(st[:, 1, 2 * nst - 1] - t0), np.median(st[:, 0, 2 * nst - 1] - t0)))
 
 
