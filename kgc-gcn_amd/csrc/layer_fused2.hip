@@ -706,21 +706,33 @@ int fused2_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  constexpr int NRT = 5;
-  const int ntiles = int((node_end - node_begin + NRT * 16 - 1) / (NRT * 16));
-  const int grid = ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus;   // persistent: one workgroup per CU
+  // Tile height: 80 rows (5 row tiles per weight fragment) unless 64-row tiles finish the launch in fewer row-steps on
+  // this chip (makespan = tiles per CU, rounded up, x rows per tile): FB15k-237's 14 541 rows are one 64-row tile on
+  // 228 CUs instead of one 80-row tile on 182.
+  const int64_t nrows = node_end - node_begin;
+  auto grid_for = [&](int rt) { const int64_t t = (nrows + rt * 16 - 1) / (rt * 16); return int(t < cus ? (t > 0 ? t : 1) : cus); };
+  auto makespan = [&](int bm) { return ((nrows + bm - 1) / bm + cus - 1) / cus * bm; };
+  int nrt = makespan(64) < makespan(80) ? 4 : 5;
+#ifdef MGCN_DIAG
+  if (const char *e = getenv("MGCN_FUSED_NRT")) nrt = atoi(e) == 4 ? 4 : 5;
+#endif
+  const int grid = grid_for(nrt);                          // persistent: one workgroup per CU
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the relation table rides in LDS when it fits beside the stage images (a third of the gather's row loads)
   const bool rel_lds = rel_dev && size_t(num_rel_rows - 1) * dim_in * 4 <= size_t(REL_LDS_MAX_BYTES);
-  // NT = 13 (the 200-wide layers) has all four variants; narrower outputs take the general one
+  // NT = 13 (the 200-wide layers) has all variants; narrower outputs take the general one
   const bool hubs = hubinfo_dev != nullptr;
   switch (pick_nt2(dim_out)) {
-    case 2: return launch2<2, NRT, false, true>(p, grid, st);
-    case 4: return launch2<4, NRT, false, true>(p, grid, st);
-    case 8: return launch2<8, NRT, false, true>(p, grid, st);
+    case 2: return launch2<2, 5, false, true>(p, grid_for(5), st);
+    case 4: return launch2<4, 5, false, true>(p, grid_for(5), st);
+    case 8: return launch2<8, 5, false, true>(p, grid_for(5), st);
     default:
-      if (rel_lds) return hubs ? launch2<13, NRT, true, true>(p, grid, st) : launch2<13, NRT, true, false>(p, grid, st);
-      return hubs ? launch2<13, NRT, false, true>(p, grid, st) : launch2<13, NRT, false, false>(p, grid, st);
+      if (nrt == 4) {
+        if (rel_lds) return hubs ? launch2<13, 4, true, true>(p, grid, st) : launch2<13, 4, true, false>(p, grid, st);
+        return hubs ? launch2<13, 4, false, true>(p, grid, st) : launch2<13, 4, false, false>(p, grid, st);
+      }
+      if (rel_lds) return hubs ? launch2<13, 5, true, true>(p, grid, st) : launch2<13, 5, true, false>(p, grid, st);
+      return hubs ? launch2<13, 5, false, true>(p, grid, st) : launch2<13, 5, false, false>(p, grid, st);
   }
 }
 
