@@ -59,6 +59,11 @@ class NativeError(RuntimeError):
     pass
 
 
+class FusedUnsupported(NativeError):
+    """mgcn_layer_fwd_fused returned MGCN_EUNSUPPORTED (misaligned operand, shape outside the kernel): callers take the
+    aggregation + dense launches instead."""
+
+
 def lib():
     """Load (once) and return the shared library; raise loudly when it is not there."""
     global _lib
@@ -311,7 +316,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
     if ee is not None and ee.numel() == 0:           # a range whose destinations have no slots: the kernel still wants
         ee = x.new_zeros((1, D))                     # a valid (never read) table pointer
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
-    _check(lib().mgcn_layer_fwd_fused(
+    rc = lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge'),
@@ -321,7 +326,10 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), int(ee_sub[2]),
         hub_info, hub_chunks, hub_c0, hub_c1,
         _dev(hub_partial, torch.float32, 'partial', True), _dev(rels_weight, torch.float32, 'rels_weight', True),
-        _dev(rel_out, torch.float32, 'rel_out', True), _stream(x)), 'mgcn_layer_fwd_fused')
+        _dev(rel_out, torch.float32, 'rel_out', True), _stream(x))
+    if rc == 3:
+        raise FusedUnsupported('mgcn_layer_fwd_fused: %s' % lib().mgcn_last_error().decode())
+    _check(rc, 'mgcn_layer_fwd_fused')
     return out
 
 

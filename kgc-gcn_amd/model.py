@@ -155,13 +155,15 @@ class MGCNConv(nn.Module):
             if wpack is not None and ee_in_slot_order:   # (a table in edge-id order takes the two-launch path)
                 # one launch: the layer, and a few extra workgroups for (rels @ W)[:-1] (model.py:107)
                 all_rel = torch.empty((rels_embs.size(0), self.out_channels), dtype=torch.float32, device=x.device)
-                _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
-                                        ee_in_slot_order, self.loop_edge.reshape(-1), wpack, self.out_channels, self.bias,
-                                        bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent,
-                                        rels_weight=self.rels_weight.detach().contiguous(), rel_out=all_rel)
-                return all_ent, all_rel
-            else:
-                self._two_launch_layer(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order, all_ent)
+                try:
+                    _native.layer_fwd_fused(csr, x, rels_embs.contiguous(), self.loop_rel.reshape(-1), edge_embs.contiguous(),
+                                            ee_in_slot_order, self.loop_edge.reshape(-1), wpack, self.out_channels, self.bias,
+                                            bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, all_ent,
+                                            rels_weight=self.rels_weight.detach().contiguous(), rel_out=all_rel)
+                    return all_ent, all_rel
+                except _native.FusedUnsupported:      # e.g. an input row stride that is not a multiple of 16 bytes
+                    pass
+            self._two_launch_layer(csr, x, rels_embs.contiguous(), edge_embs.contiguous(), ee_in_slot_order, all_ent)
             # (rels @ W)[:-1] drops the self-loop row, so the projection needs no concatenation (model.py:107)
             return all_ent, _native.matmul(rels_embs.contiguous(), self.rels_weight)
 
@@ -265,6 +267,14 @@ class MGCN(nn.Module):
 
     @staticmethod
     def _loaded_reference_order(module, incompatible_keys):
+        # the tables that were just loaded are in reference order; one that was MISSING from the state dict
+        # (strict=False) still holds its slot-ordered data: bring it back to reference order before forgetting the layout
+        if module._slot_csr is not None:
+            missing = set(incompatible_keys.missing_keys)
+            with torch.no_grad():
+                for name, p in module._edge_tables():
+                    if name in missing:
+                        p.data.copy_(p.data.index_select(0, module._slot_csr.inv_perm.to(p.device)))
         module._slot_csr = None
         module._enc_cache = None
 
@@ -279,6 +289,52 @@ class MGCN(nn.Module):
                 t = p.data if self._slot_csr is None else p.data.index_select(0, self._slot_csr.inv_perm)
                 p.data.copy_(t.index_select(0, csr.perm))
         self._slot_csr = csr
+
+    def _use_reference_order(self):
+        """Undo _use_slot_order: the per-edge tables back in reference edge-id order, in place."""
+        if self._slot_csr is None:
+            return
+        with torch.no_grad():
+            for _, p in self._edge_tables():
+                p.data.copy_(p.data.index_select(0, self._slot_csr.inv_perm.to(p.device)))
+        self._slot_csr = None
+        self._enc_cache = None
+
+    def _edge_table_ids(self):
+        return {id(p) for _, p in self._edge_tables()}
+
+    def optimizer_state_dict(self, optimizer):
+        """optimizer.state_dict() with the per-row state of the per-edge tables (Adam's exp_avg / exp_avg_sq follow the
+        parameter's in-place slot order) brought back to REFERENCE edge-id order — what main.py:160 should store as
+        'optim_dict' so that the file does not depend on this build's slot layout (hub threshold, chunking)."""
+        sd = optimizer.state_dict()
+        if self._slot_csr is None:
+            return sd
+        ids, inv = self._edge_table_ids(), self._slot_csr.inv_perm
+        index = 0
+        state = dict(sd['state'])
+        for group in optimizer.param_groups:
+            for p in group['params']:
+                if id(p) in ids and index in state:
+                    state[index] = {k: (v.index_select(0, inv.to(v.device)) if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == p.size(0)
+                                        else v) for k, v in state[index].items()}
+                index += 1
+        return {'state': state, 'param_groups': sd['param_groups']}
+
+    def load_optimizer_state_dict(self, optimizer, state_dict):
+        """Inverse of optimizer_state_dict: load a reference-order 'optim_dict' (also one written by the reference itself)
+        and lay the per-edge tables' state out in the current slot order."""
+        optimizer.load_state_dict(state_dict)
+        if self._slot_csr is None:
+            return
+        ids, perm = self._edge_table_ids(), self._slot_csr.perm
+        for group in optimizer.param_groups:
+            for p in group['params']:
+                if id(p) in ids and p in optimizer.state:
+                    st = optimizer.state[p]
+                    for k, v in list(st.items()):
+                        if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == p.size(0):
+                            st[k] = v.index_select(0, perm.to(v.device)).contiguous()
 
     # -- encoder ---------------------------------------------------------------------------------
     def _graph_facts(self, data):
@@ -307,6 +363,8 @@ class MGCN(nn.Module):
             self.entity_embedding.size(0), num_rel_rows, data.edge_index, edge_type)
         if edge_identity:
             self._use_slot_order(csr)
+        elif self._slot_csr is not None:
+            self._use_reference_order()      # this graph gathers rows by edge id: the tables must be in reference order
 
         frozen = not self.training and not torch.is_grad_enabled()
         if not frozen:

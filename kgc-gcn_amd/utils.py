@@ -74,18 +74,32 @@ def set_logger(log_path):
 
 
 def save_checkpoint(state, is_best, checkpoint_dir):
+    """utils.py:121-139. `measure` comes from np.round(...) in evaluate (main.py:92,158-162): stored as a Python float
+    so that the file holds tensors and plain numbers only."""
     os.makedirs(checkpoint_dir, exist_ok=True)
     path = os.path.join(checkpoint_dir, 'last.ckpt')
+    if isinstance(state, dict) and 'measure' in state and state['measure'] is not None:
+        state = dict(state, measure=float(state['measure']))
     torch.save(state, path)
     if is_best:
         shutil.copyfile(path, os.path.join(checkpoint_dir, 'best.ckpt'))
 
 
+def _numpy_scalar_globals():
+    """What a reference-written checkpoint pickles besides tensors: its `measure` is an np.float64 (main.py:158-162).
+    Allow-listing exactly these keeps torch.load on the no-code (weights_only) path."""
+    import numpy as np
+    core = getattr(np, '_core', None) or np.core
+    return [core.multiarray.scalar, np.dtype, type(np.dtype('float64'))]
+
+
 def load_checkpoint(checkpoint, model, optimizer=None):
     if not os.path.exists(checkpoint):
         raise FileNotFoundError("File doesn't exist {}".format(checkpoint))   # the reference raises a str (Q11)
-    ckpt = torch.load(checkpoint, map_location='cpu', weights_only=True)
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        ckpt = torch.load(checkpoint, map_location='cpu', weights_only=True)
     model.load_state_dict(ckpt['state_dict'])
     if optimizer is not None:
         optimizer.load_state_dict(ckpt['optim_dict'])
-    return ckpt.get('measure', None)
+    measure = ckpt.get('measure', None)
+    return float(measure) if measure is not None else None

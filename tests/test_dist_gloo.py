@@ -95,7 +95,7 @@ def test_sharded_counts_equal_unsharded_gloo():
                                                       kernels=TorchKernels)
         assert torch.equal(got[r][0], want_c)
         assert torch.equal(got[r][1], want_t)
-        assert int(want_c[:, 2].sum()) == 0 or True
+        assert int(want_c.sum()) > 0                         # the comparison is not over all-zero counts
 
 
 def test_shard_bounds_and_filter_index(pkg):

@@ -1,0 +1,214 @@
+"""Round-2 additions on the GPU: encoder-cache / hipGraph invalidation, the operator seam with an edge
+list that is not mirror-symmetric (model.py:82-101), slot-order bookkeeping of the per-edge tables and of the optimizer
+state, and the fall-back from the fused launch."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from .conftest import golden
+from .test_gpu_parity import DEV, _model
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_encode(oracle, sd, ei, ea):
+    return oracle.layer_forward(sd, 'conv1.', sd['entity_embedding'], ei, ea[0], sd['edge_embeddings'], sd['relation_embedding'])
+
+
+@pytest.mark.parametrize('case', ['syn_a', 'syn_b'])
+def test_encoder_cache_and_replay_follow_every_parameter_change(pkg, oracle, case):
+    """main.py:117-121 recomputes the encoder per batch; the build caches it in eval mode and replays a captured
+    hipGraph. After an optimizer step, a load_state_dict, an in-place edit of a BN statistic or of a table, the next
+    encode() must return the NEW values (cache stamp = parameter versions; the replay reads through stable pointers)."""
+    g = golden(case)
+    model, dl, params = _model(pkg, g)
+    params.cache_encoder = True
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    model.eval()
+
+    def check(tag):
+        with torch.no_grad():
+            ent, rel = model.encode(dl.graph)
+            again, _ = model.encode(dl.graph)
+        assert again.data_ptr() == ent.data_ptr(), tag            # second call: served from the cache
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        want_ent, want_rel = _oracle_encode(oracle, sd, ei, ea)
+        np.testing.assert_allclose(ent.cpu().numpy(), want_ent.numpy(), rtol=0, atol=5e-5, err_msg=tag)
+        np.testing.assert_allclose(rel.cpu().numpy(), want_rel.numpy(), rtol=0, atol=2e-5, err_msg=tag)
+        return ent.clone()
+
+    base = check('initial')
+    # (1) one optimizer step on the encoder's parameters
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    model.train()
+    trip = g.t('dl_q_test_tail_triple').to(DEV)
+    loss = model(trip[:, 0], trip[:, 1], dl.graph).mean()
+    loss.backward()
+    opt.step()
+    model.eval()
+    after_step = check('after optimizer step')
+    assert float((after_step - base).abs().max()) > 1e-4          # the step really changed the output
+    # (2) BN running statistics edited in place (what a train-mode forward does)
+    with torch.no_grad():
+        model.conv1.ent_bn.running_mean.add_(0.05)
+        model.conv1.ent_bn.running_var.mul_(1.3)
+    after_bn = check('after BN statistics change')
+    assert float((after_bn - after_step).abs().max()) > 1e-4
+    # (3) a table edited in place
+    with torch.no_grad():
+        model.edge_embeddings.mul_(1.1)
+    after_table = check('after per-edge table change')
+    assert float((after_table - after_bn).abs().max()) > 1e-5
+    # (4) load_state_dict back to the golden parameters
+    model.load_state_dict(g.state_dict(), strict=False)
+    back = check('after load_state_dict')
+    np.testing.assert_allclose(back.cpu().numpy(), g['eval_all_ent'], rtol=0, atol=3e-5)
+    # (5) .train() then .eval(): no stale cache from the train-mode forward in between
+    model.train()
+    model(trip[:, 0], trip[:, 1], dl.graph)
+    model.eval()
+    check('after a train-mode forward')
+
+
+def test_operator_seam_with_a_non_mirrored_edge_list(pkg, oracle):
+    """MGCNConv.forward accepts any [2, 2E] list split in halves by position (model.py:88-90). For a list whose second
+    half is NOT the first half reversed: the forward (eval) matches the oracle; under autograd w.r.t. x the seam raises
+    instead of returning a wrong gradient (the HIP backward walks destination runs through the reverse-edge map);
+    gradients that do not need that map (per-edge table, relations) still come out right when x needs none."""
+    N, R, E, D, O = 211, 4, 900, 20, 40
+    gen = torch.Generator().manual_seed(21)
+    ei = torch.randint(0, N, (2, 2 * E), generator=gen)           # two independent halves: not mirror-symmetric
+    et = torch.cat([torch.randint(0, R, (E,), generator=gen), torch.randint(R, 2 * R, (E,), generator=gen)])
+    sd = oracle.init_layer_state('conv1.', D, O, gen)
+    x, ee, rel = torch.randn(N, D, generator=gen), torch.randn(2 * E, D, generator=gen), torch.randn(2 * R, D, generator=gen)
+    want_ent, want_rel = oracle.layer_forward(sd, 'conv1.', x, ei, et, ee, rel)
+    conv = pkg.MGCNConv(D, O, 2 * R)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items()})
+    conv.to(DEV).eval()
+    with torch.no_grad():
+        got_ent, got_rel = conv(x.to(DEV), ei.to(DEV), et.to(DEV), None, ee.to(DEV), rel.to(DEV))
+    np.testing.assert_allclose(got_ent.cpu().numpy(), want_ent.numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(got_rel.cpu().numpy(), want_rel.numpy(), rtol=0, atol=1e-5)
+    csr = pkg.graph.csr_for_tensors(N, 2 * R + 1, ei.to(DEV), et.to(DEV))
+    assert not csr.mirrored and int(csr.mirror.max()) == -1
+    conv.train()
+    conv.drop.p = 0.0
+    with pytest.raises(pkg._native.NativeError, match='reversed'):
+        conv(x.to(DEV).requires_grad_(True), ei.to(DEV), et.to(DEV), None, ee.to(DEV), rel.to(DEV))
+    # x without gradient: the training-mode forward and the table / relation gradients against oracle autograd
+    eed, reld = ee.to(DEV).requires_grad_(True), rel.to(DEV).requires_grad_(True)
+    out, _ = conv(x.to(DEV), ei.to(DEV), et.to(DEV), None, eed, reld)
+    out.square().sum().backward()
+    ee_c, rel_c = ee.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    sd_c = {k: v.clone() for k, v in sd.items()}
+    ref, _ = oracle.layer_forward(sd_c, 'conv1.', x, ei, et, ee_c, rel_c, training=True, drop_p=0.0)
+    ref.square().sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(eed.grad.cpu().numpy(), ee_c.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(reld.grad.cpu().numpy(), rel_c.grad.numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_mirrored_flag_of_the_loader_graph(pkg):
+    g = golden('syn_a')
+    model, dl, params = _model(pkg, g)
+    assert dl.graph.csr(2 * dl.num_relation + 1).mirrored
+
+
+def test_tables_return_to_reference_order_for_a_graph_with_permuted_edge_ids(pkg, oracle):
+    """after the tables were laid out in one graph's slot order, encoding a graph whose edge ids are not the
+    identity gathers rows by edge id: the tables must first go back to reference order."""
+    g = golden('syn_a')
+    model, dl, params = _model(pkg, g)
+    model.eval()
+    with torch.no_grad():
+        first, _ = model.encode(dl.graph)
+        first = first.clone()
+    assert model._slot_csr is not None
+    E2 = dl.graph.edge_attr.size(1)
+    perm = torch.randperm(E2, generator=torch.Generator().manual_seed(5))
+    # the same edges listed with shuffled ids: edge k now reads table row perm[k]
+    g2 = pkg.Graph(edge_index=dl.graph.edge_index.clone(), edge_attr=torch.stack([dl.graph.edge_attr[0].cpu(), perm]).to(DEV))
+    g2.entity, g2.num_nodes, g2.edge_norm = dl.graph.entity, dl.graph.num_nodes, None
+    with torch.no_grad():
+        second, _ = model.encode(g2)
+    assert model._slot_csr is None                                 # reference order restored before the gather
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei, ea = g.t('dl_edge_index'), g.t('dl_edge_attr')
+    want, _ = oracle.layer_forward(sd, 'conv1.', sd['entity_embedding'], ei, ea[0], sd['edge_embeddings'].index_select(0, perm),
+                                   sd['relation_embedding'])
+    np.testing.assert_allclose(second.cpu().numpy(), want.numpy(), rtol=0, atol=5e-5)
+    with torch.no_grad():
+        third, _ = model.encode(dl.graph)                           # and back to the loader's graph
+    np.testing.assert_allclose(third.cpu().numpy(), first.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_partial_load_state_dict_keeps_untouched_tables_consistent(pkg):
+    """load_state_dict(strict=False) without the per-edge table must not leave slot-ordered data behind
+    that is later treated as reference-ordered."""
+    g = golden('syn_b')
+    model, dl, params = _model(pkg, g)
+    model.eval()
+    with torch.no_grad():
+        before, _ = model.encode(dl.graph)
+        before = before.clone()
+    partial = {k: v for k, v in g.state_dict().items() if k != 'edge_embeddings'}
+    res = model.load_state_dict(partial, strict=False)
+    assert 'edge_embeddings' in res.missing_keys
+    assert torch.equal(model.state_dict()['edge_embeddings'].cpu(), g.state_dict()['edge_embeddings'])
+    with torch.no_grad():
+        after, _ = model.encode(dl.graph)
+    assert torch.equal(after, before)
+
+
+def test_optimizer_state_travels_in_reference_order(pkg):
+    """Adam's moments of the per-edge table follow the parameter's in-place slot order; the helpers convert
+    them so that a checkpoint's optim_dict does not depend on the slot layout."""
+    g = golden('syn_b')
+    model, dl, params = _model(pkg, g)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    trip = g.t('dl_q_test_tail_triple').to(DEV)
+    model.train()
+    model(trip[:, 0], trip[:, 1], dl.graph).mean().backward()
+    opt.step()
+    assert model._slot_csr is not None
+    csr = model._slot_csr
+    raw = opt.state[model.edge_embeddings]['exp_avg'].clone()                     # slot order
+    sd = model.optimizer_state_dict(opt)
+    idx = [i for i, p in enumerate(opt.param_groups[0]['params']) if p is model.edge_embeddings][0]
+    assert torch.equal(sd['state'][idx]['exp_avg'], raw.index_select(0, csr.inv_perm))   # reference order on the way out
+    # a second model with ANOTHER slot layout (hubs split differently) loads the same optim_dict
+    other, dl2, _ = _model(pkg, g)
+    other.load_state_dict(model.state_dict())
+    csr2 = pkg.GraphCSR(csr.num_nodes, csr.num_rel_rows, dl2.graph.edge_index, dl2.graph.edge_attr[0], DEV, hub_threshold=2, hub_chunk=2)
+    other._use_slot_order(csr2)
+    opt2 = torch.optim.Adam(other.parameters(), lr=1e-3)
+    other.load_optimizer_state_dict(opt2, sd)
+    got = opt2.state[other.edge_embeddings]['exp_avg']
+    assert torch.equal(got.index_select(0, csr2.inv_perm), raw.index_select(0, csr.inv_perm))
+    assert torch.equal(other.state_dict()['edge_embeddings'], model.state_dict()['edge_embeddings'])
+
+
+def test_fused_launch_falls_back_when_an_operand_is_misaligned(pkg, oracle):
+    """a layer input whose rows are not 16-byte aligned makes mgcn_layer_fwd_fused return MGCN_EUNSUPPORTED;
+    MGCNConv.forward then takes the aggregation + dense launches instead of raising."""
+    g = golden('syn_c')
+    sd = g.state_dict()
+    ei, ea = g.t('dl_edge_index').to(DEV), g.t('dl_edge_attr').to(DEV)
+    D, O = sd['conv1.in_weight'].shape
+    conv = pkg.MGCNConv(D, O, sd['relation_embedding'].size(0), bias='conv1.bias' in sd)
+    conv.load_state_dict({k[6:]: v for k, v in sd.items() if k.startswith('conv1.')})
+    conv.to(DEV).eval()
+    csr = pkg.graph.csr_for_tensors(sd['entity_embedding'].size(0), sd['relation_embedding'].size(0) + 1, ei, ea[0])
+    table = sd['edge_embeddings'].to(DEV).index_select(0, csr.perm)
+    wide = torch.zeros((sd['entity_embedding'].size(0), D + 1), device=DEV)
+    x_bad = wide[:, 1:]                                              # row stride D + 1 floats, base + 4 bytes
+    x_bad.copy_(sd['entity_embedding'])
+    with torch.no_grad():
+        with pytest.raises(pkg._native.FusedUnsupported):
+            _, wpack = conv.derived_weights()
+            bn = conv.ent_bn
+            pkg._native.layer_fwd_fused(csr, x_bad, sd['relation_embedding'].to(DEV), conv.loop_rel.reshape(-1), table, True,
+                                        conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var,
+                                        bn.weight, bn.bias, bn.eps, torch.empty((wide.size(0), O), device=DEV))

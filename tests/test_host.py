@@ -390,6 +390,32 @@ def test_state_dict_keys_match_reference(pkg):
     assert set(two.state_dict()) - want == {k for k in two.state_dict() if 'extra' in k}
 
 
+def test_checkpoint_round_trip_with_numpy_measure(pkg, tmp_path):
+    """main.py:158-162 stores `measure` = np.round(np.float64, 5): a checkpoint written that way (by the reference or by
+    this package's training flow) must load through the no-code loader, restore the model and return the measure."""
+    g = golden('toy_small')
+    dl, params = _loader(pkg, g)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    model.load_state_dict(g.state_dict())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    measure = np.round(np.float64(0.4299600001), 5)
+    # (a) exactly what the reference's utils.save_checkpoint does: torch.save of the dict, np.float64 inside
+    ref_style = os.path.join(tmp_path, 'ref.ckpt')
+    torch.save({'state_dict': model.state_dict(), 'optim_dict': opt.state_dict(), 'measure': measure}, ref_style)
+    # (b) this package's writer
+    pkg.utils.save_checkpoint({'state_dict': model.state_dict(), 'optim_dict': opt.state_dict(), 'measure': measure}, True,
+                              str(tmp_path))
+    for path in (ref_style, os.path.join(tmp_path, 'last.ckpt'), os.path.join(tmp_path, 'best.ckpt')):
+        fresh = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+        fresh_opt = torch.optim.Adam(fresh.parameters(), lr=1e-3)
+        got = pkg.utils.load_checkpoint(path, fresh, fresh_opt)
+        assert got == float(measure)
+        for k, v in g.state_dict().items():
+            assert torch.equal(fresh.state_dict()[k].reshape(-1), v.reshape(-1)), k
+    with pytest.raises(FileNotFoundError):
+        pkg.utils.load_checkpoint(os.path.join(tmp_path, 'missing.ckpt'), model)
+
+
 def test_seeded_init_matches_reference(pkg):
     """Same construction order and initialisers as the reference (utils.py:113-118, model.py:12-22,49-70,
     132-157): with the same seed the parameters are identical, so seeded runs are comparable."""
