@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MGCN_ABI_VERSION 1
+#define MGCN_ABI_VERSION 2
 
 enum {
   MGCN_OK = 0,
@@ -141,13 +141,18 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
  * feeder) the chunk sums are first written to partial_dev [chunk_end - chunk_begin, D] by a pre-pass launch on the
  * same stream, a second launch folds every hub's chunk sums into the row of its first chunk, and the main launch
  * adds that one row per hub.
+ * Table shard (ABI 2): as in the fused launch below, ee_dev may hold only the rows a destination range needs — its
+ * in-half slots, its out-half slots, its hub slots, each a contiguous run — with ee_sub_in / ee_sub_out / ee_sub_hub such
+ * that the row of (absolute) slot s is s - ee_sub_{region}; all three are 0 with the whole table. This is what lets a
+ * rank of the destination partition hold 1/W of a table that does not fit one GPU (configs[4]: 410 GB).
  */
 int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                        const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                        int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
                        int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
                        int64_t node_begin, int64_t node_end, const int32_t *hubinfo_dev, const int32_t *chunks_dev,
-                       int64_t chunk_begin, int64_t chunk_end, float *partial_dev, void *stream);
+                       int64_t chunk_begin, int64_t chunk_end, float *partial_dev, int64_t ee_sub_in, int64_t ee_sub_out,
+                       int64_t ee_sub_hub, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) Aggregation backward (autograd through (2); driven by main.py:66). Given g = dL/dA [N, lda]

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MGCN_LIB') or os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')   # MGCN_LIB: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -23,7 +23,7 @@ _SIGNATURES = {
     'mgcn_csr_build_host': (ctypes.c_int, [_i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64,
                                            _ptr] + [_ptr] * 4),
     'mgcn_aggregate_fwd': (ctypes.c_int, [_i64, _i64, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
-                                          _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr]),
+                                          _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr]),
     'mgcn_aggregate_bwd': (ctypes.c_int, [_i64, _i64, _i32, _i32] + [_ptr] * 6 + [_i64, _ptr, _ptr] +
                            [_ptr, _i64, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_aggregate_bwd_workspace': (ctypes.c_size_t, [_i64, _i32, _i32, _i64]),
@@ -160,10 +160,14 @@ def _hub_args(csr, d, device, n0, n1):
     return _dev(csr.hubinfo, torch.int32, 'hubinfo'), _dev(csr.chunks, torch.int32, 'chunks'), c0, c1, partial
 
 
-def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None):
+def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None, ee_sub=(0, 0, 0),
+                  out_row0=0):
     """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR.
     `rel` is either the whole relation table [num_rel_rows, D] (last row = self-loop row) or, with
-    `loop_rel` [D] given separately, its first num_rel_rows-1 rows (no concatenation needed)."""
+    `loop_rel` [D] given separately, its first num_rel_rows-1 rows (no concatenation needed).
+    With `node_range` = (n0, n1), `ee` may be that range's shard of the slot-ordered table
+    (graph.GraphCSR.edge_table_shard) and `ee_sub` its three slot offsets (GraphCSR.shard_ee_sub). `out_row0`: `out`
+    holds rows [out_row0, out_row0 + out.size(0)) of the aggregate (the kernel indexes rows by global node id)."""
     N, E, D = csr.num_nodes, csr.num_edges_half, x.size(1)
     _same_device(csr.rowptr, x, rel, ee, loop_edge, out, loop_rel)
     if loop_rel is None:
@@ -173,25 +177,36 @@ def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=No
     if x.size(0) != N or rel.size(0) != csr.num_rel_rows - 1 or rel.size(1) != D or loop_rel.numel() != D:
         raise NativeError('aggregate_fwd: x %s / rel %s do not match graph (N=%d, rel rows=%d)'
                           % (tuple(x.shape), tuple(rel.shape), N, csr.num_rel_rows))
-    if ee is not None and tuple(ee.shape) != (2 * E, D):
+    ee_sub = tuple(int(v) for v in ee_sub)
+    sharded = ee_sub != (0, 0, 0) or (ee is not None and ee.size(0) != 2 * E)
+    if ee is not None and not sharded and tuple(ee.shape) != (2 * E, D):
         raise NativeError('aggregate_fwd: per-edge table %s, expected (%d, %d)' % (tuple(ee.shape), 2 * E, D))
     if not rel.is_contiguous() or (ee is not None and not ee.is_contiguous()):
         raise NativeError('aggregate_fwd: relation and per-edge tables must be contiguous')
     modes = 3 if loop_edge is not None else 2
     if loop_edge is not None and loop_edge.numel() != D:
         raise NativeError('aggregate_fwd: loop_edge must have %d elements' % D)
-    if out.size(0) != N or out.size(1) < modes * D:
-        raise NativeError('aggregate_fwd: out %s too small for (%d, %d)' % (tuple(out.shape), N, modes * D))
     n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
     if not 0 <= n0 <= n1 <= N:
         raise NativeError('aggregate_fwd: node range (%d, %d) outside [0, %d]' % (n0, n1, N))
+    out_row0 = int(out_row0)
+    if out.size(1) < modes * D or out_row0 > n0 or out_row0 + out.size(0) < n1 or (out_row0 == 0 and node_range is None and out.size(0) != N):
+        raise NativeError('aggregate_fwd: out %s (rows from %d) does not cover destinations [%d, %d) x %d columns'
+                          % (tuple(out.shape), out_row0, n0, n1, modes * D))
+    if sharded:
+        rows = csr.shard_slot_counts(n0, n1)
+        if ee is None or not ee_in_slot_order or tuple(ee.shape) != (sum(rows), D) or not ee.is_contiguous() or \
+                ee_sub != csr.shard_ee_sub(n0, n1):
+            raise NativeError('aggregate_fwd: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
+        if ee.numel() == 0:
+            ee = x.new_zeros((1, D))
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
     _check(lib().mgcn_aggregate_fwd(
         N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
-        _dev(out, torch.float32, 'out'), _ld(out), n0, n1, hub_info, hub_chunks, hub_c0, hub_c1,
-        _dev(hub_partial, torch.float32, 'partial', True), _stream(x)), 'mgcn_aggregate_fwd')
+        _dev(out, torch.float32, 'out') - out_row0 * _ld(out) * 4, _ld(out), n0, n1, hub_info, hub_chunks, hub_c0, hub_c1,
+        _dev(hub_partial, torch.float32, 'partial', True), ee_sub[0], ee_sub[1], ee_sub[2], _stream(x)), 'mgcn_aggregate_fwd')
     return out
 
 

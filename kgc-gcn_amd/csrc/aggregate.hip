@@ -60,6 +60,7 @@ struct AggArgs {
   float *partial;        // [num_chunks][D] chunk sums; after the fold, row `first chunk` holds the hub's total
   int32_t chunk0, nchunks;  // chunks [chunk0, chunk0 + nchunks) are in play; partial row = chunk - chunk0
   int64_t ee_sub_hub;       // table row of hub slot s = s - ee_sub_hub (slot-ordered table shards)
+  int64_t ee_sub[2];        // ... and of a slot of half h: s - ee_sub[h] (0 with the whole table)
 };
 
 // GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots in flight per group:
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);   // absolute slot positions
   const int beg = rp[node], end = rp[node + 1];
   const int64_t base = 0;
+  const int64_t ee_sub_mode = p.ee_sub[mode];
   for (int s = beg; s < end; s += U) {
     int4 r[U];
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
       const float *xr = p.x + int64_t(r[u].x) * p.ldx;
       const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
       const int64_t slot = base + s + u;
-      const float *er = p.ee ? p.ee + (p.ee_slot_order ? slot : int64_t(r[u].w)) * p.d : nullptr;
+      const float *er = p.ee ? p.ee + (p.ee_slot_order ? slot - ee_sub_mode : int64_t(r[u].w)) * p.d : nullptr;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int ch = lane_in_group + c * gs;
@@ -682,8 +684,10 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
                                   int32_t ee_in_slot_order, const float *loop_edge_dev, float *a_dev, int64_t lda,
                                   int64_t node_begin, int64_t node_end, const int32_t *hubinfo_dev,
                                   const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
-                                  void *stream) {
+                                  int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim > 0 && num_rel_rows > 0, "aggregate_fwd: bad sizes");
+  MGCN_REQUIRE((ee_sub_in == 0 && ee_sub_out == 0 && ee_sub_hub == 0) || (ee_dev && ee_in_slot_order),
+               "aggregate_fwd: table shard offsets need a per-edge table in slot order");
   MGCN_REQUIRE(num_nodes < (int64_t(1) << 31) - 1 && 2 * num_edges_half < (int64_t(1) << 31) - 1,
                "aggregate_fwd: sizes exceed int32");
   MGCN_REQUIRE(rowptr_dev && x_dev && a_dev && loop_rel_dev && (rel_dev || num_rel_rows == 1),
@@ -702,7 +706,7 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
                        (!loop_edge_dev || mgcn::aligned16(loop_edge_dev)) && ldx % 4 == 0 && lda % 4 == 0;
   Geometry g;
   if (!pick_geometry(dim, aligned, &g)) return mgcn::fail(MGCN_EUNSUPPORTED, "aggregate_fwd: dim %d too wide", dim);
-  AggArgs p;
+  AggArgs p = {};
   p.rowptr = rowptr_dev;
   p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.x = x_dev;
@@ -726,10 +730,11 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
   p.partial = partial_dev;
   p.chunk0 = int32_t(chunk_begin);
   p.nchunks = int32_t(num_chunks);
-  p.ee_sub_hub = 0;
+  p.ee_sub_hub = ee_sub_hub;
+  p.ee_sub[0] = ee_sub_in; p.ee_sub[1] = ee_sub_out;
   if (num_chunks > 0) {
     if (int rc = mgcn::launch_hub_partials(num_nodes, dim, num_rel_rows, rec_dev, x_dev, ldx, rel_dev, loop_rel_dev, ee_dev,
-                                           ee_in_slot_order, 0, chunks_dev, chunk_begin, chunk_end, partial_dev, stream))
+                                           ee_in_slot_order, ee_sub_hub, chunks_dev, chunk_begin, chunk_end, partial_dev, stream))
       return rc;
   }
   {

@@ -77,51 +77,117 @@ def sharded_rank_counts(x, qkey, obj, ent_shard, bias_shard, row0, filt, group=N
     return counts[rank * B:(rank + 1) * B], target[rank * B:(rank + 1) * B]
 
 
+def xavier_rows(edge_ids, num_rows, dim, seed, device, chunk=1 << 16):
+    """Rows `edge_ids` (reference edge ids, int64) of a [num_rows, dim] xavier-uniform table (utils.get_param's
+    initialiser, utils.py:113-118) that is DEFINED chunk-wise: rows [c * chunk, (c + 1) * chunk) come from a generator
+    seeded with (seed, c). Any rank can therefore materialise exactly the rows it owns, in any order, with one chunk
+    of scratch — the whole table (410 GB at configs[4]) never exists anywhere."""
+    bound = (6.0 / (num_rows + dim)) ** 0.5
+    edge_ids = edge_ids.to(device)
+    out = torch.empty((edge_ids.numel(), dim), dtype=torch.float32, device=device)
+    which = torch.div(edge_ids, chunk, rounding_mode='floor')
+    for c in torch.unique(which).tolist():
+        gen = torch.Generator(device=device)
+        gen.manual_seed(int(seed) * 1000003 + int(c))
+        block = (torch.rand((chunk, dim), generator=gen, device=device) * 2 - 1) * bound
+        sel = (which == c).nonzero(as_tuple=True)[0]
+        out[sel] = block.index_select(0, edge_ids.index_select(0, sel) - c * chunk)
+    return out
+
+
+@torch.no_grad()
+def shard_model_tables(model, csr, n0, n1, source):
+    """Fill a model built with params.edge_table_rows = sum(csr.shard_slot_counts(n0, n1)) with the rows of destinations
+    [n0, n1): in-half slots, out-half slots, hub slots (slot order). `source(layer, edge_ids) -> rows [len, D]` returns
+    table rows by reference edge id — e.g. lambda l, ids: xavier_rows(ids, 2E, D_l, seed + l, device), or a slice of
+    a state dict that is streamed from disk. Nothing of size [2E, D] is allocated."""
+    (i0, i1), (o0, o1), (h0, h1) = csr._shard_bounds(n0, n1)
+    ids = torch.cat([csr.perm[i0:i1], csr.perm[o0:o1], csr.perm[h0:h1]])
+    tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
+    for li, t in enumerate(tables):
+        if t.size(0) != ids.numel():
+            raise _native.NativeError('shard_model_tables: table %d has %d rows, destinations [%d, %d) need %d'
+                                      % (li, t.size(0), n0, n1, ids.numel()))
+        t.data.copy_(source(li, ids).to(t.device))
+    model._edge_shard = (csr, int(n0), int(n1))
+    model._slot_csr = None
+    model._enc_cache = None
+    return model
+
+
+def encode_layer_rows(layer, csr, x, rel, table_shard, n0, n1, ee_sub, out=None):
+    """Rows [n0, n1) of one layer's eval output (model.py:82-106) from this rank's table shard: the fused launch where
+    the shape allows, else the aggregation + dense launches on the range. `out` [n1 - n0, O] optional."""
+    O, bn = layer.out_channels, layer.ent_bn
+    if out is None:
+        out = torch.empty((n1 - n0, O), dtype=torch.float32, device=x.device)
+    wcat, wpack = layer.derived_weights()
+    x, rel = x.contiguous(), rel.contiguous()
+    if wpack is not None:
+        _native.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table_shard, True, layer.loop_edge.reshape(-1),
+                                wpack, O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                                node_range=(n0, n1), ee_sub=ee_sub)
+    elif n1 > n0:
+        # the aggregate of the range only ([n1 - n0, 3D]); the kernel writes rows by global node id, hence the offset view
+        agg = torch.empty((n1 - n0, 3 * layer.in_channels), dtype=torch.float32, device=x.device)
+        _native.aggregate_fwd(csr, x, rel, table_shard, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1),
+                              node_range=(n0, n1), ee_sub=ee_sub, out_row0=n0)
+        _native.dense_bn_tanh_fwd(agg, wcat, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out)
+    return out
+
+
 @torch.no_grad()
 def encode_sharded(model, graph, group=None):
-    """Destination-partitioned encoder: rank r computes rows [b_r, b_{r+1}) of every layer's output with
-    the fused layer kernel, reading only ITS shard of the slot-ordered per-edge tables (1/W of their bytes — the
-    table is what does not fit one GPU at 10^8 triples); every destination's sum is formed wholly on one rank, so the
-    rows are bit-identical to the single-GPU ones. Sources are arbitrary, so each layer output is all-gathered (RCCL)
-    before the next layer / the scorer reads it. Returns (all_ent [N, O], all_rel [2R, O]) complete on every rank."""
+    """Destination-partitioned encoder: rank r computes rows [b_r, b_{r+1}) of every layer's output,
+    reading only ITS shard of the slot-ordered per-edge tables (1/W of their bytes — the table is what does not fit one
+    GPU at 10^8 triples); every destination's sum is formed wholly on one rank, so the rows are bit-identical to the
+    single-GPU ones. Sources are arbitrary, so each layer output is all-gathered (RCCL) before the next layer / the
+    scorer reads it. Returns (all_ent [N, O], all_rel [2R, O]) complete on every rank.
+    A model built with params.edge_table_rows (dist.shard_model_tables) holds nothing but its shard; a model with
+    whole tables is sliced once per table version (a convenience for small graphs: no memory is saved then)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model.eval()
     edge_type, edge_ids = graph.edge_attr
-    ent_identity, edge_identity = model._graph_facts(graph)
     layers = [model.conv1] + list(model.conv1_extra)
-    if world == 1 or not (ent_identity and edge_identity) or not all(
-            _native.fused_supported(l.in_channels, l.out_channels) for l in layers):
-        return model.encode(graph)                              # shapes outside the fused kernel: replicated encoder
+    tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
     csr = graph.csr(model.relation_embedding.size(0) + 1)
-    model._use_slot_order(csr)
     N = csr.num_nodes
     b = csr.balanced_bounds(world)          # equal work (slots + nodes) per rank, not equal node counts (degree skew)
     n0, n1, chunk = b[rank], b[rank + 1], max(b[r + 1] - b[r] for r in range(world))
+    if model._edge_shard is not None:
+        if model._edge_shard[0] is not csr or model._edge_shard[1:] != (n0, n1):
+            raise _native.NativeError('encode_sharded: the model holds the table shard of destinations %s, this rank owns (%d, %d)'
+                                      % (model._edge_shard[1:], n0, n1))
+        shards = [t.detach() for t in tables]
+    else:
+        ent_identity, edge_identity = model._graph_facts(graph)
+        if world == 1 or not (ent_identity and edge_identity):
+            return model.encode(graph)                          # nothing to partition / ids that need gathers: replicated
+        model._use_slot_order(csr)
+        cache = model.__dict__.setdefault('_ee_shard_cache', {})
+        shards = []
+        for li, table in enumerate(tables):
+            key = (li, n0, n1, id(csr))
+            hit = cache.get(key)
+            if hit is None or hit[0] != table._version or hit[1].device != table.device:
+                hit = (table._version, csr.edge_table_shard(table.detach(), n0, n1))
+                cache[key] = hit
+            shards.append(hit[1])
     x, rel = model.entity_embedding.detach(), model.relation_embedding.detach()
-    tables = [model.edge_embeddings] + list(model.edge_embeddings_extra)
     ee_sub = csr.shard_ee_sub(n0, n1)
-    shards = model.__dict__.setdefault('_ee_shard_cache', {})   # the rank's table shards, re-sliced only when a table changes
-    for li, (layer, table) in enumerate(zip(layers, tables)):
-        _, wpack = layer.derived_weights()
-        key = (li, n0, n1, id(csr))
-        hit = shards.get(key)
-        if hit is None or hit[0] != table._version or hit[1].device != table.device:
-            hit = (table._version, csr.edge_table_shard(table.detach(), n0, n1))   # a deployment at scale keeps ONLY this
-            shards[key] = hit
-        shard = hit[1]
+    for layer, shard in zip(layers, shards):
         local = torch.zeros((chunk, layer.out_channels), dtype=torch.float32, device=x.device)
-        bn = layer.ent_bn
-        _native.layer_fwd_fused(csr, x.contiguous(), rel.contiguous(), layer.loop_rel.reshape(-1), shard, True,
-                                layer.loop_edge.reshape(-1), wpack, layer.out_channels, layer.bias, bn.running_mean,
-                                bn.running_var, bn.weight, bn.bias, bn.eps, local[:n1 - n0], node_range=(n0, n1),
-                                ee_sub=ee_sub)
-        full = torch.empty((world * chunk, layer.out_channels), dtype=torch.float32, device=x.device)
-        dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal (padded) chunks, gathered in place
-        if all(b[r + 1] - b[r] == chunk for r in range(world - 1)):
-            x = full[:N]
-        else:                                                                  # drop each rank's padding rows
-            x = torch.cat([full[r * chunk:r * chunk + b[r + 1] - b[r]] for r in range(world)], dim=0)
+        encode_layer_rows(layer, csr, x, rel, shard, n0, n1, ee_sub, out=local[:n1 - n0])
+        if world > 1:
+            full = torch.empty((world * chunk, layer.out_channels), dtype=torch.float32, device=x.device)
+            dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal (padded) chunks, gathered in place
+            if all(b[r + 1] - b[r] == chunk for r in range(world - 1)):
+                x = full[:N]
+            else:                                                              # drop each rank's padding rows
+                x = torch.cat([full[r * chunk:r * chunk + b[r + 1] - b[r]] for r in range(world)], dim=0)
+        else:
+            x = local[:N]
         rel = _native.matmul(rel.contiguous(), layer.rels_weight)
     return x, rel
 

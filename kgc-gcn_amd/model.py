@@ -232,7 +232,13 @@ class MGCN(nn.Module):
         self.params = params
         self.entity_embedding = get_param((num_entities, params.gcn_in_dim))
         self.relation_embedding = get_param((2 * num_relations, params.gcn_in_dim))
-        self.edge_embeddings = get_param((2 * num_edges, params.gcn_in_dim))
+        # params.edge_table_rows (destination partition): this process holds only ITS shard of every per-edge
+        # table — the rows of the slots of its destination range, in slot order (dist.shard_model_tables fills them) —
+        # and never allocates the [2E, D] tables (410 GB at BASELINE configs[4]). Default: the whole table, as the reference.
+        shard_rows = getattr(params, 'edge_table_rows', None)
+        table = (lambda d: get_param((2 * num_edges, d))) if shard_rows is None else \
+            (lambda d: nn.Parameter(torch.zeros((int(shard_rows), d))))
+        self.edge_embeddings = table(params.gcn_in_dim)
         self.conv1 = MGCNConv(params.gcn_in_dim, params.gcn_out_dim, num_relations * 2)
         self.conv2 = ConvE(params, num_entities)
         self.loss_fn = nn.BCELoss()
@@ -242,8 +248,8 @@ class MGCN(nn.Module):
         extra = int(getattr(params, 'gcn_layers', 1)) - 1
         self.conv1_extra = nn.ModuleList(
             [MGCNConv(params.gcn_out_dim, params.gcn_out_dim, num_relations * 2) for _ in range(extra)])
-        self.edge_embeddings_extra = nn.ParameterList(
-            [get_param((2 * num_edges, params.gcn_out_dim)) for _ in range(extra)])
+        self.edge_embeddings_extra = nn.ParameterList([table(params.gcn_out_dim) for _ in range(extra)])
+        self._edge_shard = None    # (csr, n0, n1) once dist.shard_model_tables has filled a partial table
         self._slot_csr = None      # per-edge tables are stored in this CSR's slot order (None = reference order)
         self._enc_cache = None
         self._hip_graph = None
@@ -258,6 +264,8 @@ class MGCN(nn.Module):
 
     @staticmethod
     def _to_reference_order(module, state_dict, prefix, local_metadata):
+        if module._edge_shard is not None:
+            return state_dict            # a partial table: the state dict holds this rank's shard (slot order) as it is
         if module._slot_csr is not None:
             inv = module._slot_csr.inv_perm
             for name, _ in module._edge_tables():
@@ -361,6 +369,9 @@ class MGCN(nn.Module):
         num_rel_rows = self.relation_embedding.size(0) + 1
         csr = data.csr(num_rel_rows) if hasattr(data, 'csr') else csr_for_tensors(
             self.entity_embedding.size(0), num_rel_rows, data.edge_index, edge_type)
+        if self._edge_shard is not None:
+            raise _native.NativeError('this model holds a shard of the per-edge tables (params.edge_table_rows): encode it '
+                                      'with dist.encode_sharded, which exchanges the layer outputs between the ranks')
         if edge_identity:
             self._use_slot_order(csr)
         elif self._slot_csr is not None:

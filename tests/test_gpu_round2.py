@@ -212,3 +212,66 @@ def test_fused_launch_falls_back_when_an_operand_is_misaligned(pkg, oracle):
             pkg._native.layer_fwd_fused(csr, x_bad, sd['relation_embedding'].to(DEV), conv.loop_rel.reshape(-1), table, True,
                                         conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var,
                                         bn.weight, bn.bias, bn.eps, torch.empty((wide.size(0), O), device=DEV))
+
+
+@pytest.mark.parametrize('dims', [(64, 128), (64, 256)])          # fused layers / O = 256 > 208: aggregation + dense launches
+def test_ranks_that_hold_only_their_table_shard(pkg, oracle, dims):
+    """SURVEY §8e / BASELINE configs[4]: a rank allocates ONLY the rows of the per-edge tables that its destination range
+    needs (params.edge_table_rows + dist.shard_model_tables; the rows come from a chunk-wise defined xavier table, so the
+    [2E, D] table never exists on it), and the rows it computes are torch.equal to the single-GPU ones. Three 'ranks' are
+    played in one process, layer by layer (what dist.encode_sharded does with an all-gather in between)."""
+    D, O = dims
+    N, R, E, W = 6000, 5, 150000, 3
+    tri = oracle.synthetic_triples(N, R, E, seed=3, zipf=1.0)
+    ei, ea = oracle.build_edge_list(tri, R)
+    graph = pkg.Graph(edge_index=torch.from_numpy(ei), edge_attr=torch.from_numpy(ea))
+    graph.entity, graph.num_nodes, graph.edge_norm = torch.arange(N), N, None
+    graph.to(DEV)
+    csr = graph.csr(2 * R + 1)
+    base = dict(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=8, k_h=O // 8,
+                num_filter=4, kernel_size=3, bias=False, lbl_smooth=0.1, gcn_layers=2)
+    dims_l = [D, O]
+    source = lambda li, ids: pkg.dist.xavier_rows(ids, 2 * E, dims_l[li], 100 + li, DEV, chunk=1 << 14)
+    # the single-GPU model: the same tables, whole (reference order = xavier_rows of every edge id)
+    torch.manual_seed(7)
+    full = pkg.MGCN(N, R, E, types.SimpleNamespace(**base)).to(DEV).eval()
+    with torch.no_grad():
+        for li, t in enumerate([full.edge_embeddings] + list(full.edge_embeddings_extra)):
+            t.copy_(source(li, torch.arange(2 * E)))
+        want_ent, want_rel = full.encode(graph)
+    table_bytes = sum(t.numel() * 4 for t in [full.edge_embeddings] + list(full.edge_embeddings_extra))
+    shared = {k: v for k, v in full.state_dict().items() if not k.startswith('edge_embeddings')}
+    b = csr.balanced_bounds(W)
+    models, peaks = [], []
+    for r in range(W):
+        n0, n1 = b[r], b[r + 1]
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        torch.manual_seed(7)
+        m = pkg.MGCN(N, R, E, types.SimpleNamespace(edge_table_rows=sum(csr.shard_slot_counts(n0, n1)), **base)).to(DEV).eval()
+        m.load_state_dict(shared, strict=False)
+        pkg.dist.shard_model_tables(m, csr, n0, n1, source)
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - before)
+        held = sum(t.numel() * 4 for t in [m.edge_embeddings] + list(m.edge_embeddings_extra))
+        assert abs(held / table_bytes - 1.0 / W) < 0.05                      # a third of the table bytes, not all of them
+        models.append(m)
+        with pytest.raises(pkg._native.NativeError, match='shard'):
+            m.encode(graph)                                                   # a partial table cannot be encoded alone
+    other = sum(p.numel() * 4 for k, p in full.state_dict().items() if not k.startswith('edge_embeddings'))
+    # building a rank: its shard + one layer's rows in flight + one chunk of the generator — never the whole table
+    assert max(peaks) < other + 0.75 * table_bytes, (peaks, other, table_bytes)
+    x, rel = full.entity_embedding.detach(), full.relation_embedding.detach()
+    with torch.no_grad():
+        for li in range(2):
+            rows = []
+            for r, m in enumerate(models):
+                n0, n1 = b[r], b[r + 1]
+                layer = ([m.conv1] + list(m.conv1_extra))[li]
+                table = ([m.edge_embeddings] + list(m.edge_embeddings_extra))[li]
+                rows.append(pkg.dist.encode_layer_rows(layer, csr, x, rel, table.detach(), n0, n1, csr.shard_ee_sub(n0, n1)))
+            x = torch.cat(rows, dim=0)
+            rel = pkg._native.matmul(rel.contiguous(), ([full.conv1] + list(full.conv1_extra))[li].rels_weight)
+    assert torch.equal(x, want_ent)
+    assert torch.equal(rel, want_rel)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(pkg):
     handle = ctypes.CDLL(pkg._native.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert pkg._native.lib().mgcn_abi_version() == 1
+    assert pkg._native.lib().mgcn_abi_version() == 2
 
 
 @pytest.mark.parametrize('case', ALL_CASES)
@@ -469,8 +469,8 @@ def test_abi_argument_validation_without_a_gpu(pkg):
     lib = pkg._native.lib()
     N = None
     cases = [
-        ('mgcn_aggregate_fwd', (-1, 0, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 0, N, N, 0, 0, N, N), 'bad sizes'),
-        ('mgcn_aggregate_fwd', (4, 2, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 4, N, N, 0, 0, N, N), 'null pointer'),
+        ('mgcn_aggregate_fwd', (-1, 0, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 0, N, N, 0, 0, N, 0, 0, 0, N), 'bad sizes'),
+        ('mgcn_aggregate_fwd', (4, 2, 4, 3, N, N, N, 4, N, N, N, 1, N, N, 12, 0, 4, N, N, 0, 0, N, 0, 0, 0, N), 'null pointer'),
         ('mgcn_aggregate_bwd', (4, 2, 0, 3, N, N, N, N, N, N, 0, N, N, N, 4, N, N, N, 8, N, N, N, N, 0, N), 'bad sizes'),
         ('mgcn_dense_bn_tanh_fwd', (4, 4, 4, N, 12, N, N, N, N, N, N, 1e-5, N, 4, N), 'null pointer'),
         ('mgcn_layer_fwd_fused', (4, 2, 4, 4, 3, N, N, N, 4, N, N, N, 1, N, N, N, N, N, N, N, 1e-5, N, 4, 2, 1, 0, 0, 0, N, N, 0,
