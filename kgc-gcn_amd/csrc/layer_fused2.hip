@@ -280,6 +280,10 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
               ++row;
             };
             int cbase = beg;                                   // first slot of the record chunk held in myrec
+#ifdef MGCN_DIAG
+            int bstamp = 64;
+            if (wave == 8 && stage == 1) { MGCN_STAMP(1, 63); }
+#endif
             for (int s = beg; s < end; s += UB) {
               if (s >= cbase + CH) {                           // group-uniform: next record chunk of a long range
                 cbase += CH;
@@ -302,10 +306,19 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
                 const uint32_t erow = MGCN_ABLATE(16) ? 0u : uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
                 ev[u] = *reinterpret_cast<const float4 *>(eeb + uint64_t(erow) * d32);
               }
+#ifdef MGCN_DIAG
+              if (wave == 8 && stage == 1 && bstamp < 126) { MGCN_STAMP(1, bstamp); ++bstamp; }   // batch loads issued
+#endif
               if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s partition and records
                 next_recs_issued = true;
                 prefetch_next();
               }
+#ifdef MGCN_DIAG
+              if (wave == 8 && stage == 1 && bstamp < 126) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MGCN_STAMP(1, bstamp); ++bstamp;                                                    // ... and landed
+              }
+#endif
 #pragma unroll
               for (int u = 0; u < UB; ++u) {
                 if (s + u < end) {
@@ -324,6 +337,9 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
               next_recs_issued = true;
               prefetch_next();
             }
+#ifdef MGCN_DIAG
+            if (wave == 8 && stage == 1 && bstamp < 126) { MGCN_STAMP(1, bstamp); ++bstamp; }       // batches consumed
+#endif
             while (row < e_hi) flush();  // last run, then zero rows for destinations without slots
             if (wave == 8) MGCN_STAMP(1, 2 * stage + 1);
             stage_barrier();             // end of stage: image stage & 1 is complete

@@ -61,6 +61,8 @@ def main():
          [('g%d end' % i, st[b, 1, 2 * i + 1]) for i in range(nst)] + [('epi0 start', st[b, 0, 100]), ('epi0 end', st[b, 0, 101]),
           ('epi1 start', st[b, 0, 102]), ('epi1 end', st[b, 0, 103]), ('m exit', st[b, 0, 122]), ('g exit', st[b, 1, 122])]
     print('block 100 events (cycles since entry):', ', '.join('%s %d' % (n, t - base) for n, t in sorted(ev, key=lambda e: e[1])))
+    print('block 100 gather stage 1 (in-half): start', st[b, 1, 2] - base, 'setup done', st[b, 1, 63] - base, 'batch events (issued, landed, ...):',
+          [int(v - base) for v in st[b, 1, 64:80] if v > st[b, 1, 2] and v < st[b, 1, 3] + 100000], 'stage end', st[b, 1, 3] - base)
     gw = (st[:, 1, 1:2 * nst:2] - st[:, 1, 0:2 * nst:2])
     mw = (st[:, 0, 1:2 * nst:2] - st[:, 0, 0:2 * nst:2])
     print('median gather work per stage :', np.median(gw, axis=0).astype(int).tolist())
