@@ -219,6 +219,33 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * (4t) The layer's epilogue in TRAINING mode and its backward (model.py:103-106 under .train(), driven by main.py:61-66):
+ *   z = (u_in + u_out + u_loop) / 3 (+ bias)        u_* [N, O] = the three products of model.py:116, dropout already applied
+ *   y = tanh((z - mean) * rstd * gamma + beta)      mean / rstd = BATCH statistics over the N rows (biased variance),
+ * running_mean / running_var updated as nn.BatchNorm1d does (momentum, unbiased variance); either both NULL or both given.
+ * z, y [N, O] contiguous; save_mean / save_rstd [O] are kept for the backward. Reductions over rows are two-stage with fixed
+ * row blocks (bitwise reproducible). workspace: mgcn_bn_tanh_train_workspace(N, O) bytes.
+ * Backward: given gy = dL/dy, returns gz = dL/dz [N, O], gu = gz / 3 (= dL/du_* before the dropout masks), ggamma, gbeta [O].
+ */
+size_t mgcn_bn_tanh_train_workspace(int64_t num_rows, int32_t dim_out);
+int mgcn_bn_tanh_train_fwd(int64_t num_rows, int32_t dim_out, const float *u_in_dev, const float *u_out_dev,
+                           const float *u_loop_dev, int64_t ldu, const float *bias_dev, const float *gamma_dev,
+                           const float *beta_dev, float *running_mean_dev, float *running_var_dev, float momentum, float eps,
+                           float *z_dev, float *y_dev, float *save_mean_dev, float *save_rstd_dev, float *workspace_dev,
+                           size_t workspace_bytes, void *stream);
+int mgcn_bn_tanh_train_bwd(int64_t num_rows, int32_t dim_out, const float *z_dev, const float *y_dev, const float *gy_dev,
+                           const float *save_mean_dev, const float *save_rstd_dev, const float *gamma_dev, float *gz_dev,
+                           float *gu_dev, float *ggamma_dev, float *gbeta_dev, float *workspace_dev, size_t workspace_bytes,
+                           void *stream);
+
+/* C[M, N] = A^T B for A [K, M] (lda), B [K, N] (ldb): the weight gradient of model.py:116, dW = aggregate^T g (K = number of
+ * nodes). Split over K (fixed ranges, partial products added in range order: reproducible), exact-f32 MFMA. M <= 208, N <= 256,
+ * else MGCN_EUNSUPPORTED. workspace: mgcn_matmul_tn_workspace(K, M, N) bytes. */
+size_t mgcn_matmul_tn_workspace(int64_t k, int32_t m, int32_t n);
+int mgcn_matmul_tn_f32(int64_t k, int32_t m, int32_t n, const float *a_dev, int64_t lda, const float *b_dev, int64_t ldb,
+                       float *c_dev, int64_t ldc, float *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* Plain C[M,N] = A[M,K] @ B[K,N] on the same f32 MFMA kernel (model.py:107, the relation projection). */
 int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t lda, const float *b_dev,
                     int64_t ldb, float *c_dev, int64_t ldc, void *stream);

@@ -34,6 +34,12 @@ _SIGNATURES = {
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
+    'mgcn_bn_tanh_train_workspace': (ctypes.c_size_t, [_i64, _i32]),
+    'mgcn_bn_tanh_train_fwd': (ctypes.c_int, [_i64, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr,
+                                              _ptr, _ptr, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_bn_tanh_train_bwd': (ctypes.c_int, [_i64, _i32] + [_ptr] * 11 + [ctypes.c_size_t, _ptr]),
+    'mgcn_matmul_tn_workspace': (ctypes.c_size_t, [_i64, _i32, _i32]),
+    'mgcn_matmul_tn_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_score_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _ptr]),
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
@@ -358,6 +364,65 @@ def matmul(a, b):
                                  _dev(b, torch.float32, 'b'), _ld(b), _dev(c, torch.float32, 'c'), _ld(c), _stream(a)),
            'mgcn_matmul_f32')
     return c
+
+
+def matmul_tn(a, b):
+    """C = A^T @ B for A [K, M], B [K, N] (the weight gradient dW = aggregate^T g): split-K exact-f32 MFMA kernel."""
+    _same_device(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.size(0) != b.size(0):
+        raise NativeError('matmul_tn: shapes %s^T @ %s' % (tuple(a.shape), tuple(b.shape)))
+    K, M, N = a.size(0), a.size(1), b.size(1)
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    nbytes = lib().mgcn_matmul_tn_workspace(K, M, N)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=a.device)
+    _check(lib().mgcn_matmul_tn_f32(K, M, N, _dev(a, torch.float32, 'a'), _ld(a), _dev(b, torch.float32, 'b'), _ld(b),
+                                    _dev(c, torch.float32, 'c'), _ld(c), _dev(ws, torch.float32, 'ws'), nbytes, _stream(a)),
+           'mgcn_matmul_tn_f32')
+    return c
+
+
+def matmul_tn_supported(m, n):
+    return m <= 208 and n <= 256
+
+
+def bn_tanh_train_fwd(u_in, u_out, u_loop, bias, gamma, beta, running_mean, running_var, momentum, eps):
+    """(4t) z = (u_in + u_out + u_loop) / 3 (+ bias); y = tanh(BN_batch(z)). Returns (y, z, save_mean, save_rstd); updates
+    the running statistics in place when given."""
+    N, O = u_in.shape
+    _same_device(u_in, u_out, u_loop, bias, gamma, beta, running_mean, running_var)
+    for t in (u_in, u_out, u_loop):
+        if tuple(t.shape) != (N, O) or t.stride(1) != 1 or t.stride(0) != u_in.stride(0):
+            raise NativeError('bn_tanh_train_fwd: the three products must be [N, O] with the same row stride')
+    z = torch.empty((N, O), dtype=torch.float32, device=u_in.device)
+    y = torch.empty_like(z)
+    mean = torch.empty(O, dtype=torch.float32, device=u_in.device)
+    rstd = torch.empty_like(mean)
+    nbytes = lib().mgcn_bn_tanh_train_workspace(N, O)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=u_in.device)
+    _check(lib().mgcn_bn_tanh_train_fwd(
+        N, O, _dev(u_in, torch.float32, 'u_in'), _dev(u_out, torch.float32, 'u_out'), _dev(u_loop, torch.float32, 'u_loop'),
+        u_in.stride(0), _dev(bias, torch.float32, 'bias', True), _dev(gamma, torch.float32, 'gamma'), _dev(beta, torch.float32, 'beta'),
+        _dev(running_mean, torch.float32, 'running_mean', True), _dev(running_var, torch.float32, 'running_var', True),
+        float(momentum), float(eps), _dev(z, torch.float32, 'z'), _dev(y, torch.float32, 'y'), _dev(mean, torch.float32, 'mean'),
+        _dev(rstd, torch.float32, 'rstd'), _dev(ws, torch.float32, 'ws'), nbytes, _stream(u_in)), 'mgcn_bn_tanh_train_fwd')
+    return y, z, mean, rstd
+
+
+def bn_tanh_train_bwd(z, y, gy, mean, rstd, gamma):
+    """Backward of bn_tanh_train_fwd: (gz [N, O], gu = gz / 3, ggamma [O], gbeta [O])."""
+    N, O = z.shape
+    _same_device(z, y, gy, mean, rstd, gamma)
+    gy = gy.contiguous()
+    gz, gu = torch.empty_like(z), torch.empty_like(z)
+    gg, gb = torch.empty_like(mean), torch.empty_like(mean)
+    nbytes = lib().mgcn_bn_tanh_train_workspace(N, O)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=z.device)
+    _check(lib().mgcn_bn_tanh_train_bwd(
+        N, O, _dev(z, torch.float32, 'z'), _dev(y, torch.float32, 'y'), _dev(gy, torch.float32, 'gy'), _dev(mean, torch.float32, 'mean'),
+        _dev(rstd, torch.float32, 'rstd'), _dev(gamma, torch.float32, 'gamma'), _dev(gz, torch.float32, 'gz'), _dev(gu, torch.float32, 'gu'),
+        _dev(gg, torch.float32, 'ggamma'), _dev(gb, torch.float32, 'gbeta'), _dev(ws, torch.float32, 'ws'), nbytes, _stream(z)),
+        'mgcn_bn_tanh_train_bwd')
+    return gz, gu, gg, gb
 
 
 def _score_args(x, ent, bias):

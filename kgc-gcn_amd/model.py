@@ -12,6 +12,8 @@ What runs where
   * the ConvE conv trunk (model.py:161-175): stock torch modules (MIOpen / rocBLAS), out of scope.
 There is no CPU path: tensors that are not on a GPU make the native layer raise.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,6 +44,53 @@ class _AggregateFn(torch.autograd.Function):
         gx, gee, grel = _native.aggregate_bwd(ctx.csr, x, rel, ee, g.contiguous(), want_gx=ctx.needs_input_grad[0],
                                               want_gee=ctx.needs_input_grad[2], want_grel=ctx.needs_input_grad[1])
         return gx, grel, gee, None
+
+
+class _LayerTrainFn(torch.autograd.Function):
+    """Training-mode dense step + epilogue of one layer (model.py:103-106, 116 under .train()) on the HIP kernels:
+    y = tanh(BN_batch((drop(A_in W_in) + drop(A_out W_out) + A_loop W_loop) / 3 (+ bias))). Products on the f32 MFMA
+    kernels (forward A W, backward g W^T and the split-K A^T g), batch statistics / normalisation / tanh and their
+    backward on the two-stage reduction kernels of csrc/train_layer.hip; the running statistics are updated in place.
+    Dropout masks come from torch's generator (Bernoulli keep-masks scaled by 1 / keep, as F.dropout)."""
+
+    @staticmethod
+    def forward(ctx, agg, a_loop, w_in, w_out, w_loop, bias, gamma, beta, running_mean, running_var, momentum, eps, p_drop):
+        d = w_in.size(0)
+        u_in, u_out = _native.matmul(agg[:, :d], w_in.contiguous()), _native.matmul(agg[:, d:], w_out.contiguous())
+        u_loop = _native.matmul(a_loop.contiguous(), w_loop.contiguous())
+        m_in = m_out = None
+        if p_drop > 0:
+            keep = 1.0 - p_drop
+            m_in = torch.empty_like(u_in).bernoulli_(keep).div_(keep)
+            m_out = torch.empty_like(u_out).bernoulli_(keep).div_(keep)
+            u_in, u_out = u_in * m_in, u_out * m_out
+        y, z, mean, rstd = _native.bn_tanh_train_fwd(u_in, u_out, u_loop, bias, gamma, beta, running_mean, running_var,
+                                                     momentum, eps)
+        ctx.save_for_backward(agg, a_loop, w_in, w_out, w_loop, gamma, z, y, mean, rstd, m_in, m_out)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        agg, a_loop, w_in, w_out, w_loop, gamma, z, y, mean, rstd, m_in, m_out = ctx.saved_tensors
+        d = w_in.size(0)
+        gz, gu, ggamma, gbeta = _native.bn_tanh_train_bwd(z, y, gy, mean, rstd, gamma)
+        g_in = gu * m_in if m_in is not None else gu
+        g_out = gu * m_out if m_out is not None else gu
+        need = ctx.needs_input_grad
+        g_agg = g_loop = g_win = g_wout = g_wloop = None
+        if need[0]:
+            g_agg = torch.cat([_native.matmul(g_in, w_in.t().contiguous()), _native.matmul(g_out, w_out.t().contiguous())], dim=1)
+        if need[1]:
+            g_loop = _native.matmul(gu, w_loop.t().contiguous())
+        if need[2]:
+            g_win = _native.matmul_tn(agg[:, :d], g_in)
+        if need[3]:
+            g_wout = _native.matmul_tn(agg[:, d:], g_out)
+        if need[4]:
+            g_wloop = _native.matmul_tn(a_loop.contiguous(), gu)
+        g_bias = gz.sum(0) if (ctx.has_bias and need[5]) else None
+        return g_agg, g_loop, g_win, g_wout, g_wloop, g_bias, ggamma, gbeta, None, None, None, None, None
 
 
 class _ScoreFn(torch.autograd.Function):
@@ -177,6 +226,17 @@ class MGCNConv(nn.Module):
         ee = edge_embs if ee_in_slot_order else edge_embs.index_select(0, csr.perm)
         agg = _AggregateFn.apply(x, rels, ee.contiguous(), csr)
         d = self.in_channels
+        bn = self.ent_bn
+        if self.training and bn.track_running_stats and bn.momentum is not None and bn.affine and \
+                _native.matmul_tn_supported(d, self.out_channels) and os.environ.get('MGCN_TRAIN_TORCH', '0') != '1':
+            # the whole training-mode layer on the HIP path: products, batch statistics, tanh, and their backward
+            a_loop = (x * rels[-1]) * self.loop_edge
+            all_ent = _LayerTrainFn.apply(agg, a_loop, self.in_weight, self.out_weight, self.loop_weight, self.bias, bn.weight,
+                                          bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                          self.drop.p if self.training else 0.0)
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            return all_ent, torch.matmul(rels, self.rels_weight)[:-1]
         in_res = agg[:, :d] @ self.in_weight
         out_res = agg[:, d:] @ self.out_weight
         loop_res = ((x * rels[-1]) * self.loop_edge) @ self.loop_weight

@@ -275,3 +275,71 @@ def test_ranks_that_hold_only_their_table_shard(pkg, oracle, dims):
             rel = pkg._native.matmul(rel.contiguous(), ([full.conv1] + list(full.conv1_extra))[li].rels_weight)
     assert torch.equal(x, want_ent)
     assert torch.equal(rel, want_rel)
+
+
+def test_training_layer_kernels_vs_torch_autograd(pkg):
+    """model.py:103-106,116 under .train() on the HIP path (csrc/train_layer.hip + the MFMA products) against torch's own
+    float64 autograd of the same expression: outputs, running statistics (momentum, unbiased variance), and every gradient."""
+    torch.manual_seed(5)
+    N, D, O = 5003, 100, 200
+    agg = torch.randn(N, 2 * D, device=DEV) * 0.5
+    a_loop = torch.randn(N, D, device=DEV) * 0.5
+    ws = [torch.randn(D, O, device=DEV) * 0.1 for _ in range(3)]
+    bias, gamma, beta = torch.randn(O, device=DEV) * 0.1, torch.rand(O, device=DEV) + 0.5, torch.randn(O, device=DEV) * 0.1
+    rm, rv = torch.randn(O, device=DEV) * 0.05, torch.rand(O, device=DEV) + 0.5
+    gy = torch.randn(N, O, device=DEV)
+    leaves = [t.clone().requires_grad_(True) for t in [agg, a_loop] + ws + [bias, gamma, beta]]
+    rm1, rv1 = rm.clone(), rv.clone()
+    y = pkg.model._LayerTrainFn.apply(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], leaves[5], leaves[6], leaves[7], rm1, rv1,
+                                      0.1, 1e-5, 0.0)
+    y.backward(gy)
+    ref = [t.double().clone().requires_grad_(True) for t in [agg, a_loop] + ws + [bias, gamma, beta]]
+    rm2, rv2 = rm.double().clone(), rv.double().clone()
+    out = (ref[0][:, :D] @ ref[2] + ref[0][:, D:] @ ref[3] + ref[1] @ ref[4]) / 3 + ref[5]
+    yr = torch.tanh(torch.nn.functional.batch_norm(out, rm2, rv2, ref[6], ref[7], True, 0.1, 1e-5))
+    yr.backward(gy.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(rm1.cpu().numpy(), rm2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv1.cpu().numpy(), rv2.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    names = ['agg', 'a_loop', 'w_in', 'w_out', 'w_loop', 'bias', 'gamma', 'beta']
+    for name, a, b in zip(names, leaves, ref):
+        scale = float(b.grad.abs().max()) + 1e-30
+        err = float((a.grad.double() - b.grad).abs().max())
+        # d bias is analytically zero (BN removes the column mean): what is left is the f32 cancellation error of a sum
+        # of N = 5003 terms of size ~1 (float64 autograd leaves 3e-13)
+        tol = 2e-5 * scale if name != 'bias' else 2e-3
+        assert err <= tol, (name, err, scale)
+
+
+@pytest.mark.parametrize('shape', [(40943, 100, 200), (14541, 200, 200), (777, 36, 44)])
+def test_weight_gradient_product_split_k(pkg, shape):
+    """mgcn_matmul_tn_f32 (dW = aggregate^T g): exact-f32 MFMA, split over the N rows, against float64."""
+    K, M, N = shape
+    g = torch.Generator().manual_seed(K)
+    a, b = torch.randn(K, M, generator=g).to(DEV), torch.randn(K, N, generator=g).to(DEV)
+    got = pkg._native.matmul_tn(a, b)
+    want = (a.double().t() @ b.double())
+    assert float((got.double() - want).abs().max()) <= 1e-5 * (K ** 0.5) * 4
+    wide = torch.randn(K, 2 * M, generator=g).to(DEV)                       # a column view with a row stride (the aggregate's halves)
+    assert torch.equal(pkg._native.matmul_tn(wide[:, M:], b), pkg._native.matmul_tn(wide[:, M:].contiguous(), b))
+    assert torch.equal(pkg._native.matmul_tn(a, b), got)                     # reproducible
+
+
+def test_training_layer_with_dropout_is_a_scaled_bernoulli_mask(pkg):
+    """p > 0: the keep-masks are Bernoulli(1 - p) scaled by 1 / (1 - p) (as F.dropout): with W_loop = 0 and one-hot
+    aggregates the pre-BN output exposes them; the same torch seed reproduces the same masks."""
+    N, D, O, p = 2048, 8, 16, 0.25
+    agg = torch.zeros(N, 2 * D, device=DEV)
+    agg[:, 0] = 3.0                                                          # u_in[:, c] = 3 * w_in[0, c], u_out = 0
+    w_in = torch.ones(D, O, device=DEV)
+    zeros = torch.zeros(D, O, device=DEV)
+    args = (agg, torch.zeros(N, D, device=DEV), w_in, zeros, zeros, None, torch.ones(O, device=DEV), torch.zeros(O, device=DEV),
+            torch.zeros(O, device=DEV), torch.ones(O, device=DEV), 0.1, 1e-5, p)
+    torch.manual_seed(3)
+    y1 = pkg.model._LayerTrainFn.apply(*args)
+    torch.manual_seed(3)
+    y2 = pkg.model._LayerTrainFn.apply(*args)
+    assert torch.equal(y1, y2)
+    # per column z takes two values (0 and 3 / (3 * 0.75)); after BN + tanh still two values, the dropped share is ~ p
+    low = (y1 < y1.mean(0, keepdim=True)).float().mean().item()
+    assert abs(low - p) < 0.03, low
