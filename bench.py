@@ -222,6 +222,10 @@ def main():
         result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args.shape, args.layers, N, R, E, D, O, 20.0)
         result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
 
+    if rank == 0:
+        real = real_dataset_sections(pkg, args, dev, D, O)
+        if real:
+            result['real_datasets'] = real
     if not args.no_fb and args.shape == 'wn18rr':
         del model, graph
         torch.cuda.empty_cache()
@@ -236,6 +240,31 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+
+
+def real_dataset_sections(pkg, args, dev, D, O):
+    """if the public triple files are present on the box (data/<name>/{train,valid,test}.txt relative to
+    the working directory, where the reference's loader looks: data_loader.py:57,65-66), run the same encoder step on the
+    REAL graph as well. They are not shipped (no network): on a box without them this returns {}."""
+    out = {}
+    for name in ('WN18RR', 'FB15k-237'):
+        d = os.path.join('data', name)
+        if not all(os.path.isfile(os.path.join(d, s + '.txt')) for s in ('train', 'valid', 'test')):
+            continue
+        params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=10, k_h=20,
+                                       num_filter=200, kernel_size=7, bias=False, lbl_smooth=0.1, gcn_layers=args.layers,
+                                       cache_encoder=False, device=dev, ingest_only=True)
+        dl = pkg.DataLoader(name, params)
+        dl.graph.to(dev)
+        torch.manual_seed(0)
+        model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params).to(dev).eval()
+        steps = max(args.steps, 20)
+        elapsed = timed_steps(model, dl.graph, steps, args.warmup, torch.cuda.synchronize, ramp_s=0.2)
+        eps = args.layers * (2 * dl.num_edge + dl.num_entity)
+        out[name] = {'N': dl.num_entity, 'R': dl.num_relation, 'E': dl.num_edge, 'ms_per_step': 1e3 * elapsed / steps,
+                     'value': eps * steps / elapsed, 'unit': 'edges/s'}
+        del model, dl
+    return out
 
 
 def fb_sections(pkg, args, dev, world, rank, dist, barrier, D, O):
