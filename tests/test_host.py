@@ -493,3 +493,19 @@ def test_abi_argument_validation_without_a_gpu(pkg):
     assert lib.mgcn_packed_weights_bytes(200, 200) == 3 * 7 * 13 * 3 * 64 * 16   # 128 + 72 columns: 4 + 3 k-blocks
     assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
     assert lib.mgcn_score_bce_partials(128, 40943) == 1280
+
+
+def test_chunkwise_xavier_table_rows(pkg):
+    """dist.xavier_rows: the per-edge table of a destination-partitioned run is DEFINED chunk by chunk, so a rank can
+    materialise exactly the rows it owns (any order, any subset) without the table: every subset equals the same rows of
+    the full materialisation, and the values are xavier-uniform for a [rows, dim] parameter (utils.py:113-118)."""
+    rows, dim, seed = 1000, 12, 5
+    full = pkg.dist.xavier_rows(torch.arange(rows), rows, dim, seed, 'cpu', chunk=128)
+    assert full.shape == (rows, dim)
+    bound = (6.0 / (rows + dim)) ** 0.5
+    assert float(full.abs().max()) <= bound and float(full.abs().max()) > 0.9 * bound
+    assert abs(float(full.mean())) < 0.05 * bound and abs(float(full.std()) - bound / 3 ** 0.5) < 0.05 * bound
+    ids = torch.tensor([999, 0, 127, 128, 129, 640, 5, 5, 998])
+    assert torch.equal(pkg.dist.xavier_rows(ids, rows, dim, seed, 'cpu', chunk=128), full.index_select(0, ids))
+    assert not torch.equal(pkg.dist.xavier_rows(ids, rows, dim, seed + 1, 'cpu', chunk=128), full.index_select(0, ids))
+    assert pkg.dist.xavier_rows(torch.zeros(0, dtype=torch.int64), rows, dim, seed, 'cpu').shape == (0, dim)
