@@ -63,6 +63,11 @@ def main():
     print('block 100 events (cycles since entry):', ', '.join('%s %d' % (n, t - base) for n, t in sorted(ev, key=lambda e: e[1])))
     print('block 100 gather stage 1 (in-half): start', st[b, 1, 2] - base, 'setup done', st[b, 1, 63] - base, 'batch events (issued, landed, ...):',
           [int(v - base) for v in st[b, 1, 64:80] if v > st[b, 1, 2] and v < st[b, 1, 3] + 100000], 'stage end', st[b, 1, 3] - base)
+    ss = [int(v - base) for v in st[b, 1, 64:118] if v > 0]
+    if ss:
+        print('block 100 gather step stamps (start, consumed, issued; cycles since entry):', ss)
+        d = np.diff(np.array(ss))
+        print('  consume / issue / fetch+rest durations per step:', [(int(d[i]), int(d[i + 1]), int(d[i + 2])) for i in range(0, len(d) - 2, 3)])
     gw = (st[:, 1, 1:2 * nst:2] - st[:, 1, 0:2 * nst:2])
     mw = (st[:, 0, 1:2 * nst:2] - st[:, 0, 0:2 * nst:2])
     print('median gather work per stage :', np.median(gw, axis=0).astype(int).tolist())

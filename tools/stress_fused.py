@@ -10,6 +10,7 @@ from oracle import mgcn_oracle as oracle
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 worst = 0.0
+bad = False
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     N = int(rng.integers(1, 700)); R = int(rng.integers(1, 9)); E = int(rng.integers(0, 4000))
     D = int(rng.choice([4, 8, 36, 64, 100, 128, 200, 256])); O = int(rng.choice([4, 16, 32, 60, 64, 128, 200, 208]))
@@ -46,15 +47,17 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         d = float((out - ref_out).abs().max()) if N else 0.0
         worst = max(worst, d)
         ok = d < 5e-5 and torch.equal(rel_out, ref_rel)
+        why = ('' if d < 5e-5 else ' out(rows wrong: %d)' % int(((out - ref_out).abs().max(1).values > 5e-5).sum())) + ('' if torch.equal(rel_out, ref_rel) else ' rel')
         # a random destination range with its table shard
         n0 = int(rng.integers(0, N)); n1 = int(rng.integers(n0, N + 1))
         part = torch.empty((n1 - n0, O), device=dev)
         nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), csr.edge_table_shard(table, n0, n1), True,
                             conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var, bn.weight,
                             bn.bias, bn.eps, part, node_range=(n0, n1), ee_sub=csr.shard_ee_sub(n0, n1))
+        if not torch.equal(part, out[n0:n1]): why += ' range[%d,%d)' % (n0, n1)
         ok = ok and torch.equal(part, out[n0:n1])
     else:
-        ok = True
+        ok = True; why = ''
     # oracle (CPU): layer output in the reference's order
     sd = {'conv1.' + k: v.detach().cpu() for k, v in conv.state_dict().items()}
     o_ent, o_rel = oracle.layer_forward(sd, 'conv1.', x.cpu(), ei, et, ee.cpu(), rel.cpu(), training=False)
@@ -62,7 +65,9 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     worst = max(worst, d2)
     ok = ok and d2 < 1e-4 and float((ref_rel.cpu() - o_rel).abs().max()) < 1e-4
     print('trial %2d N=%3d R=%d E=%4d D=%3d O=%3d hubs(thr=%d, chunks=%d) zipf=%.1f  fused-vs-2launch %.1e  vs oracle %.1e %s'
-          % (trial, N, R, E, D, O, thr, csr.num_chunks, zipf, d if nat.fused_supported(D, O) else -1, d2, 'ok' if ok else 'MISMATCH'))
+          % (trial, N, R, E, D, O, thr, csr.num_chunks, zipf, d if nat.fused_supported(D, O) else -1, d2, 'ok' if ok else 'MISMATCH' + why))
     if not ok:
-        sys.exit(1)
+        bad = True
+        if not os.environ.get('STRESS_KEEP_GOING'): sys.exit(1)
 print('worst deviation %.2e over all trials' % worst)
+sys.exit(1 if bad else 0)
