@@ -440,6 +440,7 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
     }
     const int G = p.G;
     auto wload = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], int g) {
+      if (MGCN_ABLATE(8)) g = 0;   // (diagnostics: every k-block re-reads the first one's fragments: 39 KB, L1-resident)
       const u32x4 *base = p.wp + (int64_t(g) * NT) * 3 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < Q; ++t) {
