@@ -588,6 +588,7 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
       }
       if (++kb == nkb_c) {
         if (wave == 0) MGCN_STAMP(0, 2 * stage + 1);
+        if (stage < 8) MGCN_STAMP(0, 32 + 8 * stage + wave);   // (diagnostics: when each of the eight MFMA waves ends the stage)
         kb = 0;
         ++stage;
         if (++chunk == nch) chunk = 0;

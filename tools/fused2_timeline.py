@@ -68,6 +68,11 @@ def main():
         print('block 100 gather step stamps (start, consumed, issued; cycles since entry):', ss)
         d = np.diff(np.array(ss))
         print('  consume / issue / fetch+rest durations per step:', [(int(d[i]), int(d[i + 1]), int(d[i + 2])) for i in range(0, len(d) - 2, 3)])
+    we = st[b, 0, 32:96].reshape(8, 8)
+    if (we > 0).any():
+        print('block 100 multiply stage ends per MFMA wave 0..7 (cycles since entry), stages 0..7:')
+        for s_ in range(min(8, nst)):
+            print('   stage %d:' % s_, [int(v - base) if v > 0 else None for v in we[s_]])
     gw = (st[:, 1, 1:2 * nst:2] - st[:, 1, 0:2 * nst:2])
     mw = (st[:, 0, 1:2 * nst:2] - st[:, 0, 0:2 * nst:2])
     print('median gather work per stage :', np.median(gw, axis=0).astype(int).tolist())
