@@ -8,66 +8,76 @@ pkg = importlib.import_module('kgc-gcn_amd'); nat = pkg._native
 sys.path.insert(0, os.path.join(ROOT))
 from oracle import mgcn_oracle as oracle
 dev = torch.device('cuda:0')
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-worst = 0.0
-bad = False
-for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
-    N = int(rng.integers(1, 700)); R = int(rng.integers(1, 9)); E = int(rng.integers(0, 4000))
-    D = int(rng.choice([4, 8, 36, 64, 100, 128, 200, 256])); O = int(rng.choice([4, 16, 32, 60, 64, 128, 200, 208]))
-    zipf = float(rng.choice([0.0, 1.2]))
-    s = rng.integers(0, N, E)
-    if zipf > 0 and N > 1:
-        pz = 1.0 / np.arange(1, N + 1) ** zipf
-        o = rng.choice(N, size=E, p=pz / pz.sum())
-    else:
-        o = rng.integers(0, N, E)
-    r = rng.integers(0, R, E)
-    ei = torch.from_numpy(np.stack((np.concatenate((s, o)), np.concatenate((o, s))))).long()
-    et = torch.from_numpy(np.concatenate((r, r + R))).long()
-    thr = int(rng.choice([0, 3, 64])); chk = int(rng.choice([2, 5, 64]))
-    csr = pkg.GraphCSR(N, 2 * R + 1, ei, et, dev, hub_threshold=thr, hub_chunk=chk)
-    torch.manual_seed(trial)
-    conv = pkg.MGCNConv(D, O, 2 * R, bias=bool(rng.integers(0, 2))).to(dev).eval()
-    with torch.no_grad():
-        conv.ent_bn.running_mean.normal_(0, 0.1); conv.ent_bn.running_var.uniform_(0.2, 1.5)
-        if conv.bias is not None: conv.bias.normal_(0, 0.1)
-    x = torch.randn(N, D, device=dev) * 0.5; rel = torch.randn(2 * R, D, device=dev) * 0.5
-    ee = torch.randn(2 * E, D, device=dev) * 0.5
-    table = ee.index_select(0, csr.perm) if E else ee
-    bn = conv.ent_bn
-    _, wpack = conv.derived_weights()
-    ref_out = torch.empty((N, O), device=dev)
-    conv._two_launch_layer(csr, x, rel, table, True, ref_out)
-    ref_rel = nat.matmul(rel, conv.rels_weight)
-    if nat.fused_supported(D, O):
-        out = torch.empty((N, O), device=dev); rel_out = torch.empty((2 * R, O), device=dev)
-        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), table, True, conv.loop_edge.reshape(-1), wpack, O,
-                            conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
-                            rels_weight=conv.rels_weight.detach().contiguous(), rel_out=rel_out)
-        d = float((out - ref_out).abs().max()) if N else 0.0
-        worst = max(worst, d)
-        ok = d < 5e-5 and torch.equal(rel_out, ref_rel)
-        why = ('' if d < 5e-5 else ' out(rows wrong: %d)' % int(((out - ref_out).abs().max(1).values > 5e-5).sum())) + ('' if torch.equal(rel_out, ref_rel) else ' rel')
-        # a random destination range with its table shard
-        n0 = int(rng.integers(0, N)); n1 = int(rng.integers(n0, N + 1))
-        part = torch.empty((n1 - n0, O), device=dev)
-        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), csr.edge_table_shard(table, n0, n1), True,
-                            conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var, bn.weight,
-                            bn.bias, bn.eps, part, node_range=(n0, n1), ee_sub=csr.shard_ee_sub(n0, n1))
-        if not torch.equal(part, out[n0:n1]): why += ' range[%d,%d)' % (n0, n1)
-        ok = ok and torch.equal(part, out[n0:n1])
-    else:
-        ok = True; why = ''
-    # oracle (CPU): layer output in the reference's order
-    sd = {'conv1.' + k: v.detach().cpu() for k, v in conv.state_dict().items()}
-    o_ent, o_rel = oracle.layer_forward(sd, 'conv1.', x.cpu(), ei, et, ee.cpu(), rel.cpu(), training=False)
-    d2 = float((ref_out.cpu() - o_ent).abs().max()) if N else 0.0
-    worst = max(worst, d2)
-    ok = ok and d2 < 1e-4 and float((ref_rel.cpu() - o_rel).abs().max()) < 1e-4
-    print('trial %2d N=%3d R=%d E=%4d D=%3d O=%3d hubs(thr=%d, chunks=%d) zipf=%.1f  fused-vs-2launch %.1e  vs oracle %.1e %s'
-          % (trial, N, R, E, D, O, thr, csr.num_chunks, zipf, d if nat.fused_supported(D, O) else -1, d2, 'ok' if ok else 'MISMATCH' + why))
-    if not ok:
-        bad = True
-        if not os.environ.get('STRESS_KEEP_GOING'): sys.exit(1)
-print('worst deviation %.2e over all trials' % worst)
-sys.exit(1 if bad else 0)
+
+
+def run(seed=0, trials=60, keep_going=False):
+    """-> (all trials ok, worst deviation); tests/test_gpu_random_shapes.py runs a short instance of it."""
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    bad = False
+    for trial in range(trials):
+        N = int(rng.integers(1, 700)); R = int(rng.integers(1, 9)); E = int(rng.integers(0, 4000))
+        D = int(rng.choice([4, 8, 36, 64, 100, 128, 200, 256])); O = int(rng.choice([4, 16, 32, 60, 64, 128, 200, 208]))
+        zipf = float(rng.choice([0.0, 1.2]))
+        s = rng.integers(0, N, E)
+        if zipf > 0 and N > 1:
+            pz = 1.0 / np.arange(1, N + 1) ** zipf
+            o = rng.choice(N, size=E, p=pz / pz.sum())
+        else:
+            o = rng.integers(0, N, E)
+        r = rng.integers(0, R, E)
+        ei = torch.from_numpy(np.stack((np.concatenate((s, o)), np.concatenate((o, s))))).long()
+        et = torch.from_numpy(np.concatenate((r, r + R))).long()
+        thr = int(rng.choice([0, 3, 64])); chk = int(rng.choice([2, 5, 64]))
+        csr = pkg.GraphCSR(N, 2 * R + 1, ei, et, dev, hub_threshold=thr, hub_chunk=chk)
+        torch.manual_seed(trial)
+        conv = pkg.MGCNConv(D, O, 2 * R, bias=bool(rng.integers(0, 2))).to(dev).eval()
+        with torch.no_grad():
+            conv.ent_bn.running_mean.normal_(0, 0.1); conv.ent_bn.running_var.uniform_(0.2, 1.5)
+            if conv.bias is not None: conv.bias.normal_(0, 0.1)
+        x = torch.randn(N, D, device=dev) * 0.5; rel = torch.randn(2 * R, D, device=dev) * 0.5
+        ee = torch.randn(2 * E, D, device=dev) * 0.5
+        table = ee.index_select(0, csr.perm) if E else ee
+        bn = conv.ent_bn
+        _, wpack = conv.derived_weights()
+        ref_out = torch.empty((N, O), device=dev)
+        conv._two_launch_layer(csr, x, rel, table, True, ref_out)
+        ref_rel = nat.matmul(rel, conv.rels_weight)
+        if nat.fused_supported(D, O):
+            out = torch.empty((N, O), device=dev); rel_out = torch.empty((2 * R, O), device=dev)
+            nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), table, True, conv.loop_edge.reshape(-1), wpack, O,
+                                conv.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                                rels_weight=conv.rels_weight.detach().contiguous(), rel_out=rel_out)
+            d = float((out - ref_out).abs().max()) if N else 0.0
+            worst = max(worst, d)
+            ok = d < 5e-5 and torch.equal(rel_out, ref_rel)
+            why = ('' if d < 5e-5 else ' out(rows wrong: %d)' % int(((out - ref_out).abs().max(1).values > 5e-5).sum())) + ('' if torch.equal(rel_out, ref_rel) else ' rel')
+            # a random destination range with its table shard
+            n0 = int(rng.integers(0, N)); n1 = int(rng.integers(n0, N + 1))
+            part = torch.empty((n1 - n0, O), device=dev)
+            nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), csr.edge_table_shard(table, n0, n1), True,
+                                conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var, bn.weight,
+                                bn.bias, bn.eps, part, node_range=(n0, n1), ee_sub=csr.shard_ee_sub(n0, n1))
+            if not torch.equal(part, out[n0:n1]): why += ' range[%d,%d)' % (n0, n1)
+            ok = ok and torch.equal(part, out[n0:n1])
+        else:
+            ok = True; why = ''
+        # oracle (CPU): layer output in the reference's order
+        sd = {'conv1.' + k: v.detach().cpu() for k, v in conv.state_dict().items()}
+        o_ent, o_rel = oracle.layer_forward(sd, 'conv1.', x.cpu(), ei, et, ee.cpu(), rel.cpu(), training=False)
+        d2 = float((ref_out.cpu() - o_ent).abs().max()) if N else 0.0
+        worst = max(worst, d2)
+        ok = ok and d2 < 1e-4 and float((ref_rel.cpu() - o_rel).abs().max()) < 1e-4
+        print('trial %2d N=%3d R=%d E=%4d D=%3d O=%3d hubs(thr=%d, chunks=%d) zipf=%.1f  fused-vs-2launch %.1e  vs oracle %.1e %s'
+              % (trial, N, R, E, D, O, thr, csr.num_chunks, zipf, d if nat.fused_supported(D, O) else -1, d2, 'ok' if ok else 'MISMATCH' + why))
+        if not ok:
+            bad = True
+            if not keep_going: return False, worst
+    print('worst deviation %.2e over all trials' % worst)
+    return not bad, worst
+
+
+if __name__ == '__main__':
+    ok, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60,
+                bool(os.environ.get('STRESS_KEEP_GOING')))
+    sys.exit(0 if ok else 1)
