@@ -212,13 +212,17 @@ __global__ __launch_bounds__(256) void agg_hub_kernel(AggArgs p, int gs_log2) {
   }
 }
 
-// Hub fold: the workgroup of a hub's FIRST chunk adds the hub's chunk sums into that chunk's row (all other
-// workgroups leave at once). Lane group j adds chunks j, j+J, j+2J, ... in that order (U loads in flight), then
-// group 0 adds the J group sums in group order: a fixed summation tree, so results are reproducible.
+// Hub fold, two levels (a hub of thousands of slots has hundreds of chunk sums: one workgroup adding them all is a chain of
+// dependent round trips). Level 1 (span = kFoldSpan, stride = 1): the workgroup of every kFoldSpan-th chunk of a hub adds
+// the next kFoldSpan chunk sums into its own row. Level 2 (stride = kFoldSpan): the workgroup of the hub's FIRST chunk adds
+// those rows into the first. Lane group j adds rows j, j+J, j+2J, ... of its span in that order (U loads in flight), then
+// group 0 adds the J group sums in group order: a fixed summation tree that depends only on the hub's chunk count.
+constexpr int kFoldSpan = 16;
 struct FoldArgs {
   const int4 *chunks;
   float *partial;
   int32_t chunk0, d;
+  int32_t level;   // 1 or 2
 };
 
 template <int VEC, int CPL>
@@ -227,8 +231,21 @@ __global__ __launch_bounds__(256) void agg_hub_fold_kernel(FoldArgs p, int gs_lo
   using T = typename V::type;
   extern __shared__ float red[];  // [J][D]
   const int4 me = p.chunks[p.chunk0 + blockIdx.x];
-  if (me.z != p.chunk0 + int(blockIdx.x) || me.w < 2) return;  // workgroup-uniform
-  float *rows = p.partial + int64_t(me.z - p.chunk0) * p.d;     // this hub's chunk sums
+  const int j0 = p.chunk0 + int(blockIdx.x) - me.z;             // this chunk's index inside its hub (workgroup-uniform)
+  if (me.w < 2) return;
+  int count, stride;
+  if (p.level == 1) {
+    if (j0 % kFoldSpan != 0 || me.w <= kFoldSpan) return;       // (a hub of at most kFoldSpan chunks is folded by level 2 alone)
+    count = me.w - j0 < kFoldSpan ? me.w - j0 : kFoldSpan;
+    stride = 1;
+  } else {
+    if (j0 != 0) return;
+    stride = me.w <= kFoldSpan ? 1 : kFoldSpan;
+    count = (me.w + stride - 1) / stride;
+  }
+  if (count < 2) return;
+  float *rows = p.partial + int64_t(me.z - p.chunk0 + j0) * p.d;   // first row of the span
+  const int64_t rstride = int64_t(stride) * p.d;
   constexpr int U = 4;
   const int gs = 1 << gs_log2, groups = 256 >> gs_log2;
   const int grp = threadIdx.x >> gs_log2, lane_in_group = threadIdx.x & (gs - 1);
@@ -236,21 +253,21 @@ __global__ __launch_bounds__(256) void agg_hub_fold_kernel(FoldArgs p, int gs_lo
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-  for (int k = grp; k < me.w; k += groups * U) {
+  for (int k = grp; k < count; k += groups * U) {
     T v[U][CPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k + u * groups;
-      if (kk >= me.w) continue;
+      if (kk >= count) continue;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int ch = lane_in_group + c * gs;
-        if (ch < nchunk) v[u][c] = V::load(rows + int64_t(kk) * p.d + ch * VEC);
+        if (ch < nchunk) v[u][c] = V::load(rows + int64_t(kk) * rstride + ch * VEC);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (k + u * groups >= me.w) continue;
+      if (k + u * groups >= count) continue;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const int ch = lane_in_group + c * gs;
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(256) void agg_hub_fold_kernel(FoldArgs p, int gs_lo
   }
   __syncthreads();
   if (grp != 0) return;
-  const int used = me.w < groups ? me.w : groups;
+  const int used = count < groups ? count : groups;
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lane_in_group + c * gs;
@@ -610,9 +627,15 @@ bool pick_geometry(int d, bool all_aligned, Geometry *g) {
 
 void launch_fold(const Geometry &g, const int4 *chunks, float *partial, int32_t chunk0, int32_t dim, int64_t num_chunks,
                  hipStream_t st) {
-  FoldArgs f = {chunks, partial, chunk0, dim};
+  FoldArgs f = {chunks, partial, chunk0, dim, 1};
   const size_t lds = size_t(256 >> g.gs_log2) * size_t(dim) * sizeof(float);
-#define MGCN_FOLD_CASE(V_, C_) hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, f, g.gs_log2)
+#define MGCN_FOLD_CASE(V_, C_)                                                                                          \
+  do {                                                                                                                  \
+    f.level = 1;                                                                                                        \
+    hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, f, g.gs_log2);    \
+    f.level = 2;                                                                                                        \
+    hipLaunchKernelGGL((agg_hub_fold_kernel<V_, C_>), dim3(unsigned(num_chunks)), dim3(256), lds, st, f, g.gs_log2);    \
+  } while (0)
   if (g.vec == 4) {
     switch (g.cpl) {
       case 1: MGCN_FOLD_CASE(4, 1); break;
