@@ -441,6 +441,7 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
     const int G = p.G;
     auto wload = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], int g) {
       if (MGCN_ABLATE(8)) g = 0;   // (diagnostics: every k-block re-reads the first one's fragments: 39 KB, L1-resident)
+      if (MGCN_ABLATE(64) && g != 0) return;   // (diagnostics: no weight loads after the first: the fragments keep their registers)
       const u32x4 *base = p.wp + (int64_t(g) * NT) * 3 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < Q; ++t) {
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
           bf16x8 a[3];
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc)
-            a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + rt * 256));
+            a[pc] = __builtin_bit_cast(bf16x8, MGCN_ABLATE(32) ? wq[0][pc] : *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + rt * 256));   // (bit 32: no LDS fragment reads)
 #pragma unroll
           for (int pr = 0; pr < 6; ++pr) {
 #pragma unroll
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
             bf16x8 a[3];
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
-              a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + xrt[j] * 256));
+              a[pc] = __builtin_bit_cast(bf16x8, MGCN_ABLATE(32) ? wx[0][pc] : *reinterpret_cast<const u32x4 *>(ap + pc * PIECE + xrt[j] * 256));
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr)
               accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[XW == 1 ? 0 : j][WP[pr]]),
