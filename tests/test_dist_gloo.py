@@ -1,4 +1,4 @@
-"""world_size-2 rehearsal of the entity-sharded scoring exchange on CPU (gloo). The three local kernels are
+"""world_size-2 and -3 rehearsal of the entity-sharded scoring exchange on CPU (gloo). The three local kernels are
 swapped for plain torch restatements (the HIP ones need a GPU); what is under test is the sharding, the
 collectives and the bookkeeping: sharded counts must equal the unsharded ones exactly (integers)."""
 import os
@@ -45,15 +45,15 @@ class TorchKernels(object):
         return torch.stack([gt, (eq & (idx < obj[:, None])).sum(1), eq.sum(1)], dim=1)
 
 
-def _problem(seed=0, B=6, N=101, O=8):
+def _problem(seed=0, B=6, N=101, O=8, world=2):
     g = torch.Generator().manual_seed(seed)
-    x = [torch.randn(B, O, generator=g) for _ in range(2)]
+    x = [torch.randn(B, O, generator=g) for _ in range(world)]
     ent, bias = torch.randn(N, O, generator=g) * 0.5, torch.randn(N, generator=g) * 0.1
-    sub = [torch.randint(0, N, (B,), generator=g) for _ in range(2)]
-    rel = [torch.randint(0, 4, (B,), generator=g) for _ in range(2)]
-    obj = [torch.randint(0, N, (B,), generator=g) for _ in range(2)]
+    sub = [torch.randint(0, N, (B,), generator=g) for _ in range(world)]
+    rel = [torch.randint(0, 4, (B,), generator=g) for _ in range(world)]
+    obj = [torch.randint(0, N, (B,), generator=g) for _ in range(world)]
     known = {}
-    for r in range(2):
+    for r in range(world):
         for b in range(B):
             known.setdefault((int(sub[r][b]), int(rel[r][b])), set()).update(
                 {int(obj[r][b])} | {int(v) for v in torch.randint(0, N, (3,), generator=g)})
@@ -65,7 +65,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     pkg = load_pkg()
-    x, ent, bias, sub, rel, obj, known = _problem()
+    x, ent, bias, sub, rel, obj, known = _problem(world=world)
     filt = pkg.dist.FilterIndex.from_known(known, 4)
     b = pkg.dist.shard_bounds(ent.size(0), world)
     counts, target = pkg.dist.sharded_rank_counts(
@@ -76,8 +76,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_counts_equal_unsharded_gloo():
-    world, port = 2, 29500 + os.getpid() % 2000
+@pytest.mark.parametrize('world', [2, 3])   # 3: uneven entity shards (101 rows: 34 + 34 + 33), three query blocks
+def test_sharded_counts_equal_unsharded_gloo(world):
+    port = 29500 + (os.getpid() + 7 * world) % 2000
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -88,7 +89,7 @@ def test_sharded_counts_equal_unsharded_gloo():
         p.join(60)
         assert p.exitcode == 0
     pkg = load_pkg()
-    x, ent, bias, sub, rel, obj, known = _problem()
+    x, ent, bias, sub, rel, obj, known = _problem(world=world)
     filt = pkg.dist.FilterIndex.from_known(known, 4)
     for r in range(world):
         want_c, want_t = pkg.dist.sharded_rank_counts(x[r], filt.query_keys(sub[r], rel[r]), obj[r], ent, bias, 0, filt,
