@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MGCN_LIB') or os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')   # MGCN_LIB: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -30,9 +30,9 @@ _SIGNATURES = {
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
-                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
-    'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
-    'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
+                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
+    'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _i32, _ptr]),
+    'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_bn_tanh_train_workspace': (ctypes.c_size_t, [_i64, _i32]),
     'mgcn_bn_tanh_train_fwd': (ctypes.c_int, [_i64, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr,
@@ -273,10 +273,15 @@ def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, o
     return out
 
 
+# `tune` argument of the fused layer entry points (include/mgcn_hip.h): 0 = automatic geometry. Read ONCE at import,
+# for A/B tools only: bits 0-3 row tiles per tile, 4-7 LDS images, 8-9 relation table in LDS, 10-11 kernel generation.
+FUSED_TUNE = int(os.environ.get('MGCN_FUSED_TUNE', '0'), 0)
+FUSED_ENABLED = os.environ.get('MGCN_FUSED', '1') != '0'
+
+
 def fused_supported(d_in, d_out):
     """Shapes the one-launch layer kernel handles (else: aggregate_fwd + dense_bn_tanh_fwd)."""
-    return (os.environ.get('MGCN_FUSED', '1') != '0' and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0
-            and d_out <= 208)
+    return FUSED_ENABLED and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0 and d_out <= 208
 
 
 def pack_weights(w_cat, out=None):
@@ -284,19 +289,20 @@ def pack_weights(w_cat, out=None):
     D, O = w_cat.size(0) // 3, w_cat.size(1)
     if w_cat.dim() != 2 or w_cat.size(0) != 3 * D or not w_cat.is_contiguous():
         raise NativeError('pack_weights: w_cat must be contiguous (3D, O)')
-    nbytes = lib().mgcn_packed_weights_bytes(D, O)
+    nbytes = lib().mgcn_packed_weights_bytes(D, O, FUSED_TUNE)
     if out is None:
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_cat.device)
     if out.numel() * 4 < nbytes:
         raise NativeError('pack_weights: out too small')
     _same_device(w_cat, out)
     _check(lib().mgcn_pack_weights(D, O, _dev(w_cat, torch.float32, 'w_cat'), _dev(out, torch.float32, 'wp'),
-                                   out.numel() * 4, _stream(w_cat)), 'mgcn_pack_weights')
+                                   out.numel() * 4, FUSED_TUNE, _stream(w_cat)), 'mgcn_pack_weights')
     return out
 
 
 def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
-                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0), rels_weight=None, rel_out=None):
+                    bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0), rels_weight=None, rel_out=None,
+                    tune=None):
     """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
     `w_packed` = pack_weights(stacked [3D, O] weights). With `node_range` = (n0, n1) only those destinations are
     computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
@@ -317,7 +323,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         if not ee_in_slot_order or tuple(ee.shape) != (sum(rows), D) or not ee.is_contiguous() or \
                 ee_sub != csr.shard_ee_sub(n0, n1):
             raise NativeError('layer_fwd_fused: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
-    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
+    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O, FUSED_TUNE):
         raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:
@@ -347,7 +353,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), int(ee_sub[2]),
         hub_info, hub_chunks, hub_c0, hub_c1,
         _dev(hub_partial, torch.float32, 'partial', True), _dev(rels_weight, torch.float32, 'rels_weight', True),
-        _dev(rel_out, torch.float32, 'rel_out', True), _stream(x))
+        _dev(rel_out, torch.float32, 'rel_out', True), FUSED_TUNE if tune is None else int(tune), _stream(x))
     if rc == 3:
         raise FusedUnsupported('mgcn_layer_fwd_fused: %s' % lib().mgcn_last_error().decode())
     _check(rc, 'mgcn_layer_fwd_fused')

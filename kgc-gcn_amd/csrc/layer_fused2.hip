@@ -624,10 +624,6 @@ __global__ __launch_bounds__(T2, 4) void layer_fused2_kernel(Args2 p) {
   }
 }
 
-#ifdef MGCN_DIAG
-#include "diag/layer_fused3.inc"
-#endif
-
 template <int NT, int NRT, bool RELLDS, bool HUBS>
 int launch2(const Args2 &p, int grid, hipStream_t st) {
   constexpr size_t lds_bytes = size_t(2) * 3 * 16 * (NRT * 16) * 16 + EPI_FLOATS * 4 + (RELLDS ? REL_LDS_MAX_BYTES : 0);
@@ -743,40 +739,6 @@ int fused2_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   hipStream_t st = static_cast<hipStream_t>(stream);
   // the relation table rides in LDS when it fits beside the stage images (a third of the gather's row loads)
   const bool rel_lds = rel_dev && size_t(num_rel_rows - 1) * dim_in * 4 <= size_t(REL_LDS_MAX_BYTES);
-#ifdef MGCN_DIAG
-  // third-generation experiment (diag/layer_fused3.inc): opt-in, D <= 256, no hubs, 32-bit byte offsets into x
-  if (getenv("MGCN_FUSED_GEN3") && dim_in <= 256 && !hubinfo_dev && num_nodes < (1 << 24) &&
-      uint64_t(num_nodes) * uint64_t(ldx) * 4u < (uint64_t(1) << 32)) {
-    const int vec = dim_in <= 128 ? 2 : 4;
-    const int nt3 = pick_nt2(dim_out);
-    const int nrt3 = nt3 == 13 ? nrt : 5;
-    const int rta = vec == 4 ? (nrt3 + 1) / 2 : nrt3;
-    const size_t buf = size_t(4) * s.kbm * 3 * (rta * 16) * 16;
-    const size_t base_bytes = 2 * buf + EPI_FLOATS * 4;
-    const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;
-    if (base_bytes <= size_t(160) * 1024) {
-      const bool rl = nt3 == 13 && rel_dev && rel_bytes > 0 && base_bytes + rel_bytes <= size_t(160) * 1024;
-      const size_t lds = base_bytes + (rl ? rel_bytes : 0);
-      const int g3 = grid_for(nrt3);
-#define MGCN_L3(NT_, NRT_, VEC_, RL_) return launch3<NT_, NRT_, VEC_, RL_>(p, g3, lds, st)
-      if (nt3 == 13) {
-        if (vec == 2) {
-          if (nrt3 == 4) { if (rl) MGCN_L3(13, 4, 2, true); MGCN_L3(13, 4, 2, false); }
-          if (rl) MGCN_L3(13, 5, 2, true);
-          MGCN_L3(13, 5, 2, false);
-        }
-        if (nrt3 == 4) { if (rl) MGCN_L3(13, 4, 4, true); MGCN_L3(13, 4, 4, false); }
-        if (rl) MGCN_L3(13, 5, 4, true);
-        MGCN_L3(13, 5, 4, false);
-      }
-      if (nt3 == 8) { if (vec == 2) MGCN_L3(8, 5, 2, false); MGCN_L3(8, 5, 4, false); }
-      if (nt3 == 4) { if (vec == 2) MGCN_L3(4, 5, 2, false); MGCN_L3(4, 5, 4, false); }
-      if (vec == 2) MGCN_L3(2, 5, 2, false);
-      MGCN_L3(2, 5, 4, false);
-#undef MGCN_L3
-    }
-  }
-#endif
   // NT = 13 (the 200-wide layers) has all variants; narrower outputs take the general one
   const bool hubs = hubinfo_dev != nullptr;
   switch (pick_nt2(dim_out)) {

@@ -1,0 +1,832 @@
+// Fused layer forward (eval), third generation — aggregation + dense step + epilogue in ONE launch (gfx950);
+// replaces model.py:29-30, 99-107, 111-118 for one run of destination rows per workgroup.
+//
+// One 1024-thread workgroup per CU (16 waves x 128 VGPRs), each owning ONE CONTIGUOUS run of destination rows
+// (rows_per_wg, a multiple of 16: 40 943 rows on 256 CUs = 160 rows each), walked in tiles of BM = 16 * NRT rows; the
+// last tile of a run may be shorter (its absent row tiles are skipped by both roles), so no tile height loses rows to
+// quantisation. Two roles:
+//   waves 8-15  GATHER    sixteen 32-lane groups; a lane holds NCH float4 of a row (columns 4 * lane and, NCH = 2,
+//               128 + 4 * lane): ONE slot walk covers 128 * NCH columns of the layer input, so a 200-wide layer is
+//               walked once (the second generation walked every slot twice, 512 + 288 bytes of each row). The tile's
+//               rows are dealt to the groups by work; a group sums its rows' slots in slot order (the sums of
+//               agg_fwd_kernel) and writes each finished row, split exactly into three bf16 pieces, to an LDS image.
+//   waves 0-7   MULTIPLY  v_mfma_f32_16x16x32_bf16 on the six significant products of the split operands (f32-faithful:
+//               see layer_fused2.hip / DESIGN.md), weights pre-split and pre-packed, streamed from L2 one k-block ahead;
+//               epilogue tanh(acc * scale + shift) (model.py:103-106) on the accumulators.
+// Stage = (mode, pass of 128 * NCH columns). Images are EXACTLY as wide as the pass (ceil(width / 8) 16-byte chunk
+// columns, not 128 / 256 columns): a 100-wide image of 80 rows is 50 KB, so THREE fit beside the relation table.
+// The roles are coupled by a ring of nimg images with two LDS counters each (rows written / rows consumed), not by a
+// workgroup barrier: the gather runs up to nimg - 1 stages ahead of the multiply, a fast wave never waits for a slow
+// one of its own role, and a tile's epilogue overlaps the next tile's gather. Every spin is bounded.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "mgcn_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T3 = 1024;
+constexpr int SPIN_LIMIT = 1 << 22;   // bounded spins: a protocol error ends in wrong numbers, never in a hung wave
+
+struct Args3 {
+  const int32_t *rowptr;
+  const int4 *rec;
+  const float *x, *rel, *loop_rel, *ee, *loop_edge;
+  const u32x4 *wp;        // packed weights [G][NT][3][64] (8 bf16 per lane), layer_fused2.hip pack2_kernel
+  const float *bias, *bn_mean, *bn_var, *bn_gamma, *bn_beta;
+  float *out;
+  int64_t ldx, ldo;
+  int32_t n, d, o, rel_rows;
+  int32_t node0, node1;   // destinations [node0, node1) are this launch's share; out row 0 = node0
+  int32_t ee_sub[2];      // slot-order per-edge table shard: row of (absolute) slot s of half h = s - ee_sub[h]
+  const int2 *hubinfo;    // [2][N] (first chunk, chunk count) or null
+  const float *partial;   // folded hub totals (pre-pass), row (first chunk - chunk0)
+  int32_t chunk0;
+  const float *rw;        // relation projection: rels_weight [D, O] (model.py:107) or null
+  float *rel_out;         // [rel_rows - 1, O]
+  int32_t npass, nkb_last, kbp, kbm, G;   // passes per mode, k-blocks of the last pass / of a full pass / per mode / per tile
+  int32_t ncc;            // 16-byte chunk columns of a stage image (8 bf16 each)
+  int32_t rows_per_wg, nimg;
+  float bn_eps;
+#ifdef MGCN_DIAG
+  unsigned long long *diag;   // [grid][16 waves][4]: cycles in the kernel, cycles waiting for an image, waits, stages
+#endif
+};
+#ifdef MGCN_DIAG
+#define DIAG_NOW() __builtin_readcyclecounter()
+#else
+#define DIAG_NOW() 0ull
+#endif
+
+__device__ __forceinline__ float tanh3_(float v) {   // exp2 + rcp, 7 VALU per value (as layer_fused2.hip)
+  const float t = __builtin_amdgcn_exp2f(fabsf(v) * -2.885390081777927f);
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
+}
+
+// Exact three-way split of an f32 into bf16 pieces by truncation (hi + mid + lo == v bit for bit for finite v; a
+// non-finite v gives NaN pieces, i.e. a NaN output row where the exact-f32 path may give +-1: documented in DESIGN.md).
+__device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2);
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) {   // {even >> 16, odd >> 16}
+  return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+__device__ __forceinline__ float4 f4mul3(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4axpy(float4 s, float4 m, float w) {
+  return make_float4(s.x + m.x * w, s.y + m.y * w, s.z + m.z * w, s.w + m.w * w);
+}
+
+// LDS counters: [0..3] rows-written per image, [4..7] rows-consumed per image, [8] one-time tables ready
+__device__ __forceinline__ void wait_ge_(const uint32_t *c, uint32_t need) {
+  for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
+    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (v >= need) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void signal_add(uint32_t *c, int lane) {
+  asm volatile("" ::: "memory");   // the wave's LDS operations are issued in program order; LDS executes them in order
+  if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+template <int NT, int NRT, int NCH, bool RELLDS>
+__global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
+  constexpr int BM = NRT * 16;
+  constexpr int UB = 4 / NCH;           // slots per gather batch: 8 row loads of 16 B per lane in flight either way
+  constexpr int CH = 32;                // slots served by one record chunk (lane i: slot cbase + i)
+  constexpr int OP = NT * 16;           // padded output width
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+  const int piece = p.ncc * BM * 16;    // bytes of one bf16 piece of an image: [chunk column][row][16 B]
+  const int buf = 3 * piece;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(lds3 + p.nimg * buf);
+  float *epi = reinterpret_cast<float *>(cnt + 16);   // [scale | shift] x OP: the epilogue as one fma per value
+  float *rel_lds = epi + 2 * OP;                      // [rel_rows - 1][D] when RELLDS
+
+  const int bid = int(blockIdx.x), nblk = int(gridDim.x);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nimg = p.nimg;
+  const int row_lo = p.node0 + bid * p.rows_per_wg;                        // this workgroup's run of destinations
+  const int row_hi = row_lo + p.rows_per_wg < p.node1 ? row_lo + p.rows_per_wg : p.node1;
+  const int myrows = row_hi > row_lo ? row_hi - row_lo : 0;
+  const int my_tiles = (myrows + BM - 1) / BM;
+  const int npass = p.npass;
+
+  if (tid < 16) cnt[tid] = 0;
+  __syncthreads();   // the only workgroup barrier: nothing is in flight yet
+#ifdef MGCN_DIAG
+  const unsigned long long t_begin = DIAG_NOW();
+  unsigned long long t_wait = 0, n_wait = 0, t_load = 0, n_load = 0;
+  auto wait_ge = [&](const uint32_t *c, uint32_t need) __attribute__((always_inline)) {
+    const unsigned long long t0 = DIAG_NOW();
+    wait_ge_(c, need);
+    t_wait += DIAG_NOW() - t0;
+    ++n_wait;
+  };
+  auto diag_end = [&]() __attribute__((always_inline)) {
+    if (p.diag && lane == 0) {
+      unsigned long long *d = p.diag + (int64_t(bid) * 16 + wave) * 4;
+      d[0] = DIAG_NOW() - t_begin; d[1] = t_wait; d[2] = wave >= 8 ? t_load : n_wait; d[3] = wave >= 8 ? n_load : t_begin;
+    }
+  };
+#else
+  auto wait_ge = [](const uint32_t *c, uint32_t need) __attribute__((always_inline)) { wait_ge_(c, need); };
+  auto diag_end = [] () {};
+#endif
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------------------------------ GATHER
+    const int gtid = tid - 512;
+    const int grp = gtid >> 5, lig = gtid & 31;
+    const int glane0 = lane & 32;
+    const int qcol = lig >> 1, frot = (qcol >> 1) & 7;     // (chunk column 16 j + qcol rotates like qcol)
+    const int wbase = qcol * BM * 16 + (lig & 1) * 8;
+    const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
+    bool wr[NCH];                                           // this lane's chunk column j exists in the image
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) wr[j] = 16 * j + qcol < p.ncc;
+
+    auto write_row = [&](unsigned char *img, int row, const float4 (&v)[NCH], const bool (&ok)[NCH]) __attribute__((always_inline)) {
+      const int rr = ((row & ~15) + (((row & 15) + frot) & 15)) * 16;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        if (wr[j]) {
+          uint32_t h[4], m[4], l[4];
+          split3(ok[j] ? v[j].x : 0.f, h[0], m[0], l[0]);
+          split3(ok[j] ? v[j].y : 0.f, h[1], m[1], l[1]);
+          split3(ok[j] ? v[j].z : 0.f, h[2], m[2], l[2]);
+          split3(ok[j] ? v[j].w : 0.f, h[3], m[3], l[3]);
+          unsigned char *dst = img + wbase + j * (256 * BM) + rr;
+          *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+          *reinterpret_cast<uint2 *>(dst + piece) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+          *reinterpret_cast<uint2 *>(dst + 2 * piece) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+        }
+      }
+    };
+    // ring position of the next stage this wave fills
+    int s_img = 0;
+    uint32_t s_round = 0;
+    auto acquire = [&]() __attribute__((always_inline)) {
+      if (s_round > 0) wait_ge(cnt + 4 + s_img, 8u * s_round);   // all 8 MFMA waves are done with the image's last use
+      return lds3 + s_img * buf;
+    };
+    auto publish = [&]() __attribute__((always_inline)) {
+      signal_add(cnt + s_img, lane);
+      if (++s_img == nimg) { s_img = 0; ++s_round; }
+    };
+    // Edge stages: the tile's rows are dealt to the 16 lane groups by WORK: group g takes the rows whose work prefix
+    // P(i) = slots before row i + c * i falls into [g, g + 1) * P(rows) / 16 (c = cost of an empty row, raised with the
+    // tile's slot count so that no group gets more than 31 rows). Every row's slots are summed by ONE group in slot
+    // order, so sums do not depend on the partition, the tile or the launch. Lane l holds the tile's row pointers
+    // l, l + 32, l + 64 (clamped); pointers and the group's first slot records are fetched one (tile, mode) ahead.
+    struct RowPtrs { int a, b, c; };
+    auto tile_rows16 = [&](int it_) {
+      const int left = myrows - it_ * BM;
+      const int r = left < BM ? left : BM;
+      return (r + 15) & ~15;
+    };
+    auto rp_of = [&](int it_, int mode_) {
+      const int32_t *rp = p.rowptr + int64_t(mode_) * (p.n + 1);
+      const int row0 = row_lo + it_ * BM;
+      auto at = [&](int i) {
+        int node = row0 + (i < BM ? i : BM);
+        node = node < row_hi ? node : row_hi;
+        return rp[node];
+      };
+      RowPtrs r;
+      r.a = at(lig); r.b = at(lig + 32); r.c = at(lig + 64);
+      return r;
+    };
+    auto rp_get = [&](const RowPtrs &r, int idx) {      // idx group-uniform, 0..BM: the tile's row pointer idx
+      const int from = glane0 + (idx & 31);
+      const int va = __shfl(r.a, from), vb = __shfl(r.b, from), vc = __shfl(r.c, from);
+      return idx < 32 ? va : (idx < 64 ? vb : vc);
+    };
+    struct Part { int lo, hi, rp; };                     // rows [lo, hi) of the tile; rp: lane l holds row pointer lo + min(l, hi - lo)
+    auto partition = [&](const RowPtrs &r, int nr) {     // nr = rows of the tile rounded up to 16
+      const int base = __shfl(r.a, glane0);
+      const int tot = rp_get(r, nr) - base;
+      const int c = 2 > (tot >> 8) + 1 ? 2 : (tot >> 8) + 1;
+      const int ptot = tot + c * nr;
+      const int thr_lo = (grp * ptot) >> 4, thr_hi = ((grp + 1) * ptot) >> 4;
+      int lo = 0, hi = 0;
+      const int vals[3] = {r.a, r.b, r.c};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lig + 32 * k;
+        const int pw = (vals[k] - base) + c * i;
+        const unsigned long long blo = __ballot(i < nr && pw < thr_lo), bhi = __ballot(i < nr && pw < thr_hi);
+        lo += __popc(uint32_t(blo >> glane0));
+        hi += __popc(uint32_t(bhi >> glane0));
+      }
+      Part q;
+      q.lo = lo; q.hi = hi;
+      const int idx = lo + (lig < hi - lo ? lig : hi - lo);
+      const int from = glane0 + (idx & 31);
+      const int va = __shfl(r.a, from), vb = __shfl(r.b, from), vc = __shfl(r.c, from);
+      q.rp = idx < 32 ? va : (idx < 64 ? vb : vc);
+      return q;
+    };
+    auto rec_chunk = [&](int cbeg, int end) {   // lane i: record of slot cbeg + i (clamped to the range's last slot)
+      int4 r = make_int4(0, 0, 0, 0);
+      if (end > cbeg) r = p.rec[(cbeg + lig < end) ? cbeg + lig : end - 1];
+      return r;
+    };
+    Part cur = {0, 0, 0};
+    int4 currec = make_int4(0, 0, 0, 0);
+    if (my_tiles > 0) {
+      cur = partition(rp_of(0, 0), tile_rows16(0));
+      currec = rec_chunk(__shfl(cur.rp, glane0), __shfl(cur.rp, glane0 + (cur.hi - cur.lo)));
+    }
+    bool tables_ready = !RELLDS;
+    for (int it = 0; it < my_tiles; ++it) {
+      const int r0 = row_lo + it * BM;
+      const int nr = tile_rows16(it);
+      // stage order per tile: self loop, in-half, out-half (the multiply walks the k-blocks in this order too)
+      for (int mi = 0; mi < 3; ++mi) {
+        const int mode = mi == 0 ? 2 : mi - 1;
+        if (mode < 2) {
+          if (!tables_ready) {          // the relation table is put into LDS by the MFMA waves during the first stage
+            wait_ge(cnt + 8, 8u);
+            tables_ready = true;
+          }
+          const int myrp = cur.rp, e_lo = cur.lo, e_hi = cur.hi, e_n = cur.hi - cur.lo;   // this group's rows [e_lo, e_hi)
+          const int4 firstrec = currec;
+          const int ee_sub_mode = p.ee_sub[mode];
+          const bool has_next = mode == 0 || it + 1 < my_tiles;   // next (tile, mode) with records
+          RowPtrs nrp = {0, 0, 0};
+          if (has_next) nrp = rp_of(mode == 0 ? it : it + 1, mode == 0 ? 1 : 0);
+          const int nnr = mode == 0 ? nr : (it + 1 < my_tiles ? tile_rows16(it + 1) : 16);
+          Part nxt = {0, 0, 0};
+          bool next_recs_issued = false;
+          int4 nrec = make_int4(0, 0, 0, 0);
+          auto prefetch_next = [&]() __attribute__((always_inline)) {   // the next (tile, mode)'s partition and first records
+            if (has_next) {
+              nxt = partition(nrp, nnr);
+              nrec = rec_chunk(__shfl(nxt.rp, glane0), __shfl(nxt.rp, glane0 + (nxt.hi - nxt.lo)));
+            }
+          };
+          int2 myhub = make_int2(-1, 0);                                  // lane i: hub chunks of destination e_lo + i
+          {
+            const int node = r0 + e_lo + lig;
+            if (p.hubinfo && lig < e_n && node < row_hi) myhub = p.hubinfo[int64_t(mode) * p.n + node];
+          }
+          const int beg = __shfl(myrp, glane0), end = __shfl(myrp, glane0 + e_n);
+          for (int pass = 0; pass < npass; ++pass) {
+            unsigned char *img = acquire();
+            bool col_ok[NCH];
+            int coff[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+              const int c_ = pass * (128 * NCH) + j * 128 + lig * 4;
+              col_ok[j] = c_ < p.d;
+              coff[j] = col_ok[j] ? c_ : 0;   // lanes past the row width repeat columns 0-3 and store zeros (or nothing)
+            }
+            const float *relbase = RELLDS ? rel_lds : p.rel;
+            int4 myrec = firstrec;
+            int row = e_lo, nb = __shfl(myrp, glane0 + 1);
+            float4 sum[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto flush = [&]() __attribute__((always_inline)) {   // the run of destination `row` is complete (group-uniform)
+              if (p.hubinfo) {     // a hub's own run is empty: its folded total sits in the row of its first chunk
+                const int first = __shfl(myhub.x, glane0 + (row - e_lo)), hcnt = __shfl(myhub.y, glane0 + (row - e_lo));
+                if (hcnt > 0) {
+#pragma unroll
+                  for (int j = 0; j < NCH; ++j) {
+                    const float4 ps = *reinterpret_cast<const float4 *>(p.partial + int64_t(first - p.chunk0) * p.d + coff[j]);
+                    sum[j] = make_float4(sum[j].x + ps.x, sum[j].y + ps.y, sum[j].z + ps.z, sum[j].w + ps.w);
+                  }
+                }
+              }
+              write_row(img, row, sum, col_ok);
+#pragma unroll
+              for (int j = 0; j < NCH; ++j) sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+              ++row;
+            };
+            int cbase = beg;                                   // first slot of the record chunk held in myrec
+            for (int s = beg; s < end; s += UB) {
+              if (s >= cbase + CH) {                           // group-uniform: next record chunk of a long range
+                cbase += CH;
+                myrec = rec_chunk(cbase, end);
+              }
+              int rsrc[UB], rtyp[UB], rnrm[UB];
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                const int from = glane0 + (((s + u < end) ? s + u : end - 1) - cbase);
+                rsrc[u] = __shfl(myrec.x, from);
+                rtyp[u] = __shfl(myrec.y, from);
+                rnrm[u] = __shfl(myrec.z, from);
+              }
+              float4 xv[UB][NCH], rv[UB][NCH], ev[UB][NCH];
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                const uint32_t erow = uint32_t(((s + u < end) ? s + u : end - 1) - ee_sub_mode);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                  xv[u][j] = *reinterpret_cast<const float4 *>(p.x + coff[j] + uint64_t(uint32_t(rsrc[u])) * ldx32);
+                  if (!RELLDS) rv[u][j] = *reinterpret_cast<const float4 *>(p.rel + coff[j] + uint64_t(uint32_t(rtyp[u])) * d32);
+                  ev[u][j] = *reinterpret_cast<const float4 *>(p.ee + coff[j] + uint64_t(erow) * d32);
+                }
+              }
+              if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s partition and records
+                next_recs_issued = true;
+                prefetch_next();
+              }
+#ifdef MGCN_DIAG
+              {
+                const unsigned long long t0 = DIAG_NOW();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t_load += DIAG_NOW() - t0;
+                ++n_load;
+              }
+#endif
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                if (s + u < end) {
+                  while (s + u >= nb) {
+                    flush();
+                    nb = __shfl(myrp, glane0 + (row - e_lo) + 1);
+                  }
+                  const float wgt = __int_as_float(rnrm[u]);
+#pragma unroll
+                  for (int j = 0; j < NCH; ++j) {
+                    const float4 rr = RELLDS ? *reinterpret_cast<const float4 *>(relbase + coff[j] + uint32_t(rtyp[u]) * d32) : rv[u][j];
+                    sum[j] = f4axpy(sum[j], f4mul3(f4mul3(xv[u][j], rr), ev[u][j]), wgt);
+                  }
+                }
+              }
+            }
+            if (!next_recs_issued) {
+              next_recs_issued = true;
+              prefetch_next();
+            }
+            while (row < e_hi) flush();  // last run, then zero rows for destinations without slots
+            publish();                   // this wave's rows of the image are written
+          }
+          cur = nxt;
+          currec = nrec;
+        } else {  // self loop: (x * loop_rel) * loop_edge, model.py:91-94,101; group g owns rows g * NRT .. + NRT of the tile
+          for (int pass = 0; pass < npass; ++pass) {
+            unsigned char *img = acquire();
+            bool col_ok[NCH];
+            int coff[NCH];
+            float4 lr[NCH], le[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+              const int c_ = pass * (128 * NCH) + j * 128 + lig * 4;
+              col_ok[j] = c_ < p.d;
+              coff[j] = col_ok[j] ? c_ : 0;
+              lr[j] = *reinterpret_cast<const float4 *>(p.loop_rel + coff[j]);
+              le[j] = *reinterpret_cast<const float4 *>(p.loop_edge + coff[j]);
+            }
+            const int g_lo = grp * NRT;
+            float4 xs[NRT][NCH];
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) {
+              const int node = (r0 + g_lo + i < row_hi) ? r0 + g_lo + i : row_hi - 1;   // rows past the run: computed, never stored
+#pragma unroll
+              for (int j = 0; j < NCH; ++j) xs[i][j] = *reinterpret_cast<const float4 *>(p.x + int64_t(node) * p.ldx + coff[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) {
+              if (g_lo + i < nr) {
+                float4 v[NCH];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) v[j] = f4mul3(f4mul3(xs[i][j], lr[j]), le[j]);
+                write_row(img, g_lo + i, v, col_ok);
+              }
+            }
+            publish();
+          }
+        }
+      }
+    }
+    // all_rel = rel @ rels_weight (model.py:107), by the gather waves once their last stage is in LDS (the MFMA waves
+    // still have stages and the last epilogue to go). One item = one relation row x 16 columns per wave: the four
+    // 16-lane groups run the four K quarters of small_matmul_kernel's arithmetic (sequential fmaf chains), the partial
+    // sums are added in quarter order — values bit-identical to the separate launch, one load round trip per 32 k.
+    if (p.rel_out) {
+      const int rows = p.rel_rows - 1, k = p.d, n = p.o;
+      const int ncg = (n + 15) / 16, items = rows * ncg;
+      const int kper = (k + 3) / 4;
+      const int qd = lane >> 4;
+      const int k0 = qd * kper, k1 = (k0 + kper < k) ? k0 + kper : k;
+      for (int item = (wave - 8) * nblk + bid; item < items; item += nblk * 8) {
+        const int row = item / ncg, col = (item - row * ncg) * 16 + (lane & 15);
+        const bool ok = col < n;
+        const float *ap = p.rel + int64_t(row) * k;
+        const float *bp = p.rw + (ok ? col : 0);
+        float a = 0.f;
+        constexpr int UR = 32;
+        for (int i0 = 0; i0 < kper; i0 += UR) {
+          float av[UR], bv[UR];
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int kk = k0 + i0 + u;
+            const int kc = (i0 + u < kper && kk < k1) ? kk : 0;
+            av[u] = ap[kc];
+            bv[u] = bp[int64_t(kc) * n];
+          }
+#pragma unroll
+          for (int u = 0; u < UR; ++u) {
+            const int kk = k0 + i0 + u;
+            if (i0 + u < kper && kk < k1) a = fmaf(av[u], bv[u], a);
+          }
+        }
+        const float q1 = __shfl(a, (lane & 15) + 16), q2 = __shfl(a, (lane & 15) + 32), q3 = __shfl(a, (lane & 15) + 48);
+        if (qd == 0 && ok) p.rel_out[int64_t(row) * n + col] = ((a + q1) + q2) + q3;
+      }
+    }
+    diag_end();
+  } else {
+    // ------------------------------------------------------------------------------------------ MULTIPLY
+    auto multiply = [&](auto Hc) __attribute__((always_inline)) {
+    constexpr int H = decltype(Hc)::value;
+    // Column group sg = wave & 3 (the SIMD) owns NT/4 column tiles; its two waves split them: half H = 0 takes the
+    // first ceil, half H = 1 the rest plus the group's share of the NT % 4 left-over column tiles, dealt as single
+    // (column tile, row tile) units. Two MFMA waves per SIMD: one's fragment waits are the other's issue slots.
+    constexpr int QALL = NT / 4, R = NT % 4;
+    constexpr int QA = (QALL + 1) / 2;
+    constexpr int Q = H == 0 ? QA : QALL - QA;       // this wave's whole column tiles
+    constexpr int QF = Q > 0 ? Q : 1;
+    constexpr int NX = H == 1 ? R * NRT : 0;         // single units shared out round-robin over the four H = 1 waves
+    constexpr int XE = (NX + 3) / 4;                 // ... at most XE per wave
+    constexpr int XF = XE > 0 ? XE : 1;
+    constexpr int XW = (R == 1) ? 1 : XF;            // weight fragments for them (R == 1: all in one column tile)
+    const int w = wave & 3;
+    const int r = lane & 15, gq = lane >> 4;
+    const int ct0 = w * QALL + (H == 0 ? 0 : QA);
+    int xct[XF], xrt[XF];
+    bool xok[XF];
+#pragma unroll
+    for (int j = 0; j < XF; ++j) {
+      const int e = 4 * j + w;
+      xok[j] = XE > 0 && e < NX;
+      xct[j] = xok[j] ? 4 * QALL + e / NRT : 0;
+      xrt[j] = xok[j] ? e % NRT : -1;
+    }
+    const int G = p.G;
+    auto wload = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], int g) {
+      const u32x4 *base = p.wp + (int64_t(g) * NT) * 3 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < Q; ++t) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) wq[t][pc] = base[((ct0 + t) * 3 + pc) * 64];
+      }
+      if (XE > 0) {
+#pragma unroll
+        for (int j = 0; j < XW; ++j) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) wx[j][pc] = base[(xct[j] * 3 + pc) * 64];
+        }
+      }
+    };
+    // Three NAMES for two live fragment sets: a k-block first issues the loads of the NEXT k-block into the set that
+    // died one k-block ago, then multiplies with its own (loaded one k-block earlier). G is a multiple of 3, so the
+    // rotation closes per tile with no conditional code between the k-blocks.
+    u32x4 wq0[QF][3], wx0[XW][3], wq1[QF][3], wx1[XW][3], wq2[QF][3], wx2[XW][3];
+
+    f32x4 acc[NRT][QF], accx[XF];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+        for (int t = 0; t < QF; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < XF; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // lane holds out[row = 16 rt + r][16 ct + 4 gq .. + 3] (operands swapped: W is the MFMA's A operand)
+    auto store_unit = [&](f32x4 a, int node, int col, const float4 &sc, const float4 &sh) {
+      if (node < row_hi) {
+        const float4 v = make_float4(tanh3_(fmaf(a[0], sc.x, sh.x)), tanh3_(fmaf(a[1], sc.y, sh.y)),
+                                     tanh3_(fmaf(a[2], sc.z, sh.z)), tanh3_(fmaf(a[3], sc.w, sh.w)));
+        *reinterpret_cast<float4 *>(p.out + int64_t(node - p.node0) * p.ldo + col) = v;
+      }
+    };
+    auto epilogue = [&](int it_) {
+      const int node0_ = row_lo + it_ * BM + r;
+      auto column_tile = [&](int ct, auto &&body) {
+        const int col = ct * 16 + 4 * gq;
+        if (col < p.o) body(col, *reinterpret_cast<const float4 *>(epi + col), *reinterpret_cast<const float4 *>(epi + OP + col));
+      };
+#pragma unroll
+      for (int t = 0; t < Q; ++t) {
+        column_tile(ct0 + t, [&](int col, const float4 &sc, const float4 &sh) {
+#pragma unroll
+          for (int rt = 0; rt < NRT; ++rt) store_unit(acc[rt][t], node0_ + rt * 16, col, sc, sh);
+        });
+      }
+      if (XE > 0) {
+#pragma unroll
+        for (int j = 0; j < XF; ++j) {
+          if (xok[j])
+            column_tile(xct[j], [&](int col, const float4 &sc, const float4 &sh) { store_unit(accx[j], node0_ + xrt[j] * 16, col, sc, sh); });
+        }
+      }
+    };
+
+    // (Every workgroup walks the k-blocks in the same order: a row's sum must not depend on which workgroup, tile or
+    // launch — whole graph or one rank's destination range — computes it.)
+    int kb = 0, pass = 0;
+    int nkb_ = 0, npass_ = 0, nmode = 0;          // the k-block after the current one: (mode, pass, ordinal)
+    auto advance_next = [&]() {
+      const int n = (npass_ == npass - 1) ? p.nkb_last : p.kbp;
+      if (++nkb_ == n) {
+        nkb_ = 0;
+        if (++npass_ == npass) {
+          npass_ = 0;
+          nmode = nmode == 2 ? 0 : nmode + 1;
+        }
+      }
+    };
+    auto gindex = [&]() {   // (packed weights are mode-major in the order in-half, out-half, self loop; stages run loop, in, out)
+      const int mode_ = nmode == 0 ? 2 : nmode - 1;
+      return mode_ * p.kbm + p.kbp * npass_ + nkb_;
+    };
+    wload(wq0, wx0, gindex());
+    advance_next();
+    // once per workgroup, by the MFMA waves while the first stage is gathered: the epilogue's per-column vectors
+    // (model.py:103-106 as one fma: tanh(acc * scale + shift)) and, when it fits, the relation table; published through
+    // the `ready` counter.
+    if (H == 0) {
+      for (int c = (wave & 3) * 64 + lane; c < OP; c += 256) {
+        const bool in = c < p.o;
+        const float inv = in ? __builtin_amdgcn_rsqf(p.bn_var[c] + p.bn_eps) * p.bn_gamma[c] : 0.f;
+        constexpr float third = 1.0f / 3.0f;   // (sum of the three modes) / 3, model.py:103, as a multiplication (<= 1 ulp)
+        epi[c] = inv * third;
+        epi[OP + c] = in ? ((p.bias ? p.bias[c] : 0.f) - p.bn_mean[c]) * inv + p.bn_beta[c] : 0.f;
+      }
+    }
+    if (RELLDS) {
+      const int n4 = ((p.rel_rows - 1) * p.d) >> 2;
+      for (int i = wave * 64 + lane; i < n4; i += 512)
+        reinterpret_cast<float4 *>(rel_lds)[i] = reinterpret_cast<const float4 *>(p.rel)[i];
+    }
+    signal_add(cnt + 8, lane);
+    int m_img = 0;
+    uint32_t m_round = 0;
+    int nrt_eff = NRT;
+    auto kblock = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], u32x4 (&nq)[QF][3], u32x4 (&nx)[XW][3]) {
+      wload(nq, nx, gindex());           // the k-block after this one (wraps into the next tile: same weights)
+      advance_next();
+      const int nkb_c = (pass == npass - 1) ? p.nkb_last : p.kbp;
+      if (kb == 0) wait_ge(cnt + m_img, 8u * (m_round + 1));   // all 8 gather waves have written their rows of the image
+      int qc = 4 * kb + gq;
+      qc = qc < p.ncc ? qc : p.ncc - 1;   // columns past the image (last k-block): any finite value of the row, their weights are zero
+      const unsigned char *ap = lds3 + m_img * buf + (qc * BM + ((r + ((qc >> 1) & 7)) & 15)) * 16;
+      // the six products, small terms first: (w piece, a piece) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
+      constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, AP[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        if (Q > 0 && rt < nrt_eff) {
+          bf16x8 a[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * piece + rt * 256));
+#pragma unroll
+          for (int pr = 0; pr < 6; ++pr) {
+#pragma unroll
+            for (int t = 0; t < Q; ++t)
+              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[t][WP[pr]]), a[AP[pr]],
+                                                                   acc[rt][t], 0, 0, 0);
+          }
+        }
+      }
+      if (XE > 0) {   // this wave's single units: their own fragment reads (row tile = a wave-uniform offset)
+#pragma unroll
+        for (int j = 0; j < XF; ++j) {
+          if (xok[j] && xrt[j] < nrt_eff) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * piece + xrt[j] * 256));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+              accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[XW == 1 ? 0 : j][WP[pr]]),
+                                                                a[AP[pr]], accx[j], 0, 0, 0);
+          }
+        }
+      }
+      if (++kb == nkb_c) {               // the stage's image is consumed: hand it back to the gather
+        signal_add(cnt + 4 + m_img, lane);
+        if (++m_img == nimg) { m_img = 0; ++m_round; }
+        kb = 0;
+        if (++pass == npass) pass = 0;
+      }
+    };
+    wait_ge(cnt + 8, 8u);   // epilogue vectors (written by four of these waves) are in LDS
+    for (int it = 0; it < my_tiles; ++it) {
+      zero_acc();
+      {
+        const int left = myrows - it * BM;
+        nrt_eff = left < BM ? (left + 15) >> 4 : NRT;
+      }
+      for (int g0 = 0; g0 < G; g0 += 3) {
+        kblock(wq0, wx0, wq1, wx1);
+        kblock(wq1, wx1, wq2, wx2);
+        kblock(wq2, wx2, wq0, wx0);
+      }
+      epilogue(it);   // the tile's images are already back with the gather, which is one or two stages ahead
+    }
+    diag_end();
+    };
+    if (wave < 4) multiply(std::integral_constant<int, 0>{});
+    else multiply(std::integral_constant<int, 1>{});
+  }
+}
+
+constexpr int NT3 = 13;   // column tiles of the multiply role: O <= 208 (narrower outputs ride along zero-padded)
+
+// wp[((g * NT + ct) * 3 + piece) * 64 + lane] = 8 bf16: W[mode * D + 32 kbi + 8 (lane >> 4) + i][16 ct + (lane & 15)],
+// i = 0..7, zero outside; g = mode * kbm + kbi (k-block kbi of the mode: 32 consecutive input columns).
+__global__ __launch_bounds__(256) void pack3_kernel(const float *__restrict__ w, u32x4 *__restrict__ wp, int d, int o,
+                                                    int kbm, int nt, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, piece = (idx >> 6) % 3, ct = ((idx >> 6) / 3) % nt, g = (idx >> 6) / (3 * nt);
+  const int mode = g / kbm, kbi = g - mode * kbm;
+  const int col = ct * 16 + (lane & 15), k0 = 32 * kbi + 8 * (lane >> 4);
+  uint32_t bits[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i;
+    const float v = (k < d && col < o) ? w[(int64_t(mode) * d + k) * o + col] : 0.f;
+    uint32_t h, m, l;
+    split3(v, h, m, l);
+    bits[i] = piece == 0 ? h : piece == 1 ? m : l;
+  }
+  u32x4 r;
+  r.x = pack_hi16(bits[0], bits[1]);
+  r.y = pack_hi16(bits[2], bits[3]);
+  r.z = pack_hi16(bits[4], bits[5]);
+  r.w = pack_hi16(bits[6], bits[7]);
+  wp[idx] = r;
+}
+
+struct Shape3 {
+  int nch, npass, nkb_last, kbp, kbm, G, ncc;
+};
+Shape3 shape3(int d) {
+  Shape3 s;
+  s.nch = d > 128 ? 2 : 1;
+  const int wpass = 128 * s.nch;
+  s.npass = (d + wpass - 1) / wpass;
+  const int wlast = d - wpass * (s.npass - 1);
+  s.nkb_last = (wlast + 31) / 32;
+  s.kbp = 4 * s.nch;
+  s.kbm = s.kbp * (s.npass - 1) + s.nkb_last;
+  s.G = 3 * s.kbm;
+  const int w0 = d < wpass ? d : wpass;
+  s.ncc = (w0 + 7) / 8;
+  return s;
+}
+
+constexpr size_t LDS_MAX = size_t(160) * 1024;
+
+#ifdef MGCN_DIAG
+unsigned long long *diag_buf3() {
+  static unsigned long long *buf = nullptr;
+  if (!buf) {
+    if (hipMalloc(&buf, 1024 * 16 * 4 * 8) != hipSuccess) buf = nullptr;
+    else (void)hipMemset(buf, 0, 1024 * 16 * 4 * 8);
+  }
+  return buf;
+}
+#endif
+
+size_t lds_bytes3(const Shape3 &s, int nrt, int nimg, int nt, size_t rel_bytes) {
+  return size_t(nimg) * 3 * s.ncc * (nrt * 16) * 16 + 64 + size_t(2) * nt * 16 * 4 + rel_bytes;
+}
+
+template <int NT, int NRT, int NCH, bool RELLDS>
+int launch3(const Args3 &p, int grid, size_t lds, hipStream_t st) {
+  // (the attribute is sticky per device and raising it costs a few microseconds: set on every launch, no state kept)
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&layer_fused3_kernel<NT, NRT, NCH, RELLDS>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_MAX)) != hipSuccess)
+    return mgcn::fail(MGCN_ELAUNCH, "layer_fused3: cannot reserve %zu bytes of LDS", LDS_MAX);
+  hipLaunchKernelGGL((layer_fused3_kernel<NT, NRT, NCH, RELLDS>), dim3(unsigned(grid)), dim3(T3), lds, st, p);
+  MGCN_CHECK_LAUNCH("layer_fused3_kernel");
+  return MGCN_OK;
+}
+
+template <int NT, int NRT, int NCH>
+int launch3_rel(const Args3 &p, int grid, size_t lds, bool rel_lds, hipStream_t st) {
+  if (rel_lds) return launch3<NT, NRT, NCH, true>(p, grid, lds, st);
+  return launch3<NT, NRT, NCH, false>(p, grid, lds, st);
+}
+
+template <int NT, int NCH>
+int launch3_nrt(const Args3 &p, int nrt, int grid, size_t lds, bool rel_lds, hipStream_t st) {
+  if (nrt == 3) return launch3_rel<NT, 3, NCH>(p, grid, lds, rel_lds, st);
+  if (nrt == 4) return launch3_rel<NT, 4, NCH>(p, grid, lds, rel_lds, st);
+  return launch3_rel<NT, 5, NCH>(p, grid, lds, rel_lds, st);
+}
+
+}  // namespace
+
+#ifdef MGCN_DIAG
+extern "C" int mgcn_diag_fused3(unsigned long long *host_out) {   // [1024][16][4] of the LAST gen-3 launch (diagnostics build)
+  unsigned long long *b = diag_buf3();
+  if (!b) return 1;
+  return hipMemcpy(host_out, b, 1024 * 16 * 4 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+#endif
+
+namespace mgcn {
+
+bool fused3_takes(int32_t dim_in, int32_t dim_out) {
+  return dim_in > 0 && dim_in % 4 == 0 && dim_in <= 1024 && dim_out > 0 && dim_out % 4 == 0 && dim_out <= 16 * NT3;
+}
+
+size_t fused3_packed_bytes(int32_t dim_in, int32_t) { return size_t(shape3(dim_in).G) * NT3 * 3 * 64 * 16; }
+
+int fused3_pack(int32_t dim_in, int32_t dim_out, const float *w_dev, void *wp_dev, void *stream) {
+  const Shape3 s = shape3(dim_in);
+  const int total = s.G * NT3 * 3 * 64;
+  hipLaunchKernelGGL(pack3_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w_dev,
+                     reinterpret_cast<u32x4 *>(wp_dev), dim_in, dim_out, s.kbm, NT3, total);
+  MGCN_CHECK_LAUNCH("pack3_kernel");
+  return MGCN_OK;
+}
+
+// tune: 0 = automatic; bits 0-3 row tiles per tile (3 / 4 / 5), bits 4-7 images (2 / 3), bits 8-9 relation table in LDS
+// (1 = never, 2 = whenever it fits): for A/B runs (tools/), never needed for correctness.
+int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
+                  const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
+                  const float *loop_rel_dev, const float *ee_dev, const float *loop_edge_dev, const void *wp_dev,
+                  const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev, const float *bn_gamma_dev,
+                  const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
+                  int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
+                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream) {
+  const Shape3 s = shape3(dim_in);
+  Args3 p = {};
+  p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
+  p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;
+  p.wp = reinterpret_cast<const u32x4 *>(wp_dev);
+  p.bias = bias_dev; p.bn_mean = bn_mean_dev; p.bn_var = bn_var_dev; p.bn_gamma = bn_gamma_dev; p.bn_beta = bn_beta_dev;
+  p.out = out_dev; p.ldx = ldx; p.ldo = ldo;
+  p.n = int32_t(num_nodes); p.d = dim_in; p.o = dim_out; p.rel_rows = num_rel_rows;
+  p.node0 = int32_t(node_begin); p.node1 = int32_t(node_end);
+  p.ee_sub[0] = int32_t(ee_sub_in); p.ee_sub[1] = int32_t(ee_sub_out);
+  p.hubinfo = reinterpret_cast<const int2 *>(hubinfo_dev); p.partial = partial_dev; p.chunk0 = int32_t(chunk_begin);
+  p.rw = rel_out_dev ? rels_weight_dev : nullptr; p.rel_out = rel_out_dev;
+  p.npass = s.npass; p.nkb_last = s.nkb_last; p.kbp = s.kbp; p.kbm = s.kbm; p.G = s.G; p.ncc = s.ncc;
+  p.bn_eps = bn_eps;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  // one contiguous run of rows per workgroup, a multiple of 16; one workgroup per CU
+  const int64_t nrows = node_end - node_begin;
+  int64_t rpw = ((nrows + cus - 1) / cus + 15) / 16 * 16;
+  if (rpw < 16) rpw = 16;
+  const int grid = int(nrows > 0 ? (nrows + rpw - 1) / rpw : 1);
+  p.rows_per_wg = int32_t(rpw);
+  const int nt = NT3;
+  const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;
+  // Geometry: the tallest tile (weight fragments feed 6 * NRT MFMAs) that leaves room for three images, else for two;
+  // the relation table rides in LDS when it fits beside them (a third of the gather's row loads). Tiles taller than
+  // the run are pointless.
+  const int t_nrt = tune & 15, t_img = (tune >> 4) & 15, t_rel = (tune >> 8) & 3;
+  int nrt = 0, nimg = 0;
+  bool rel_lds = false;
+  const int nrt_cap = rpw >= 80 ? 5 : rpw >= 64 ? 4 : 3;
+  auto fits = [&](int a, int b, bool r) { return lds_bytes3(s, a, b, nt, r ? rel_bytes : 0) <= LDS_MAX; };
+  const bool rel_wanted = rel_bytes > 0 && rel_bytes <= size_t(32) * 1024 && t_rel != 1;
+  if (t_nrt || t_img) {
+    nrt = t_nrt ? t_nrt : nrt_cap;
+    nimg = t_img ? t_img : 2;
+    rel_lds = rel_wanted && fits(nrt, nimg, true);
+    if (nrt < 3 || nrt > 5 || nimg < 2 || nimg > 4 || !fits(nrt, nimg, rel_lds))
+      return mgcn::fail(MGCN_EINVAL, "layer_fwd_fused: tune %d does not fit the LDS", tune);
+  } else {
+    for (int want_rel = rel_wanted ? 1 : 0; want_rel >= 0 && !nrt; --want_rel) {
+      for (int a = nrt_cap; a >= 3 && !nrt; --a) {
+        for (int b = 3; b >= 2 && !nrt; --b) {
+          if (fits(a, b, want_rel != 0)) { nrt = a; nimg = b; rel_lds = want_rel != 0; }
+        }
+      }
+    }
+    if (!nrt) return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: no tile geometry fits the LDS (D=%d O=%d)", dim_in, dim_out);
+  }
+  p.nimg = nimg;
+#ifdef MGCN_DIAG
+  p.diag = diag_buf3();
+#endif
+  const size_t lds = lds_bytes3(s, nrt, nimg, nt, rel_lds ? rel_bytes : 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (s.nch == 1) return launch3_nrt<NT3, 1>(p, nrt, grid, lds, rel_lds, st);
+  return launch3_nrt<NT3, 2>(p, nrt, grid, lds, rel_lds, st);
+}
+
+}  // namespace mgcn

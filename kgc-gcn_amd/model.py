@@ -5,14 +5,16 @@ checkpoints load.
 What runs where
   * neighbour aggregation (model.py:99-101,111-118 + identity gathers 29-30, norms 72-80): HIP, forward
     and backward (kgc-gcn_amd/csrc/aggregate.hip) over the slot-ordered CSR of graph.GraphCSR;
-  * eval-mode layer epilogue (model.py:103-107): the f32-MFMA dense step fused with /3, bias, BN, tanh
-    (csrc/dense.hip). In training mode (batch statistics, dropout) the dense step + BN go through
-    torch's own GPU ops so autograd covers them;
+  * eval-mode layer (model.py:99-107): ONE launch, aggregation + dense step (six bf16-split MFMA products, f32-faithful)
+    + /3, bias, BN, tanh (csrc/layer_fused3.hip); shapes it does not take: aggregation launch + exact-f32 MFMA dense
+    launch (csrc/dense.hip). In training mode (batch statistics, dropout) the products, the BN reductions, tanh and
+    their backward run on csrc/train_layer.hip kernels behind torch.autograd.Function (only the dropout masks are torch's);
   * full-graph scoring (model.py:177-179) and the filtered rank counts (main.py:122-126): HIP;
   * the ConvE conv trunk (model.py:161-175): stock torch modules (MIOpen / rocBLAS), out of scope.
 There is no CPU path: tensors that are not on a GPU make the native layer raise.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -59,7 +61,10 @@ class _LayerTrainFn(torch.autograd.Function):
         u_in, u_out = _native.matmul(agg[:, :d], w_in.contiguous()), _native.matmul(agg[:, d:], w_out.contiguous())
         u_loop = _native.matmul(a_loop.contiguous(), w_loop.contiguous())
         m_in = m_out = None
-        if p_drop > 0:
+        if p_drop >= 1.0:                       # F.dropout(p=1) is all zeros (1 / keep would be 0 / 0)
+            m_in, m_out = torch.zeros_like(u_in), torch.zeros_like(u_out)
+            u_in, u_out = m_in, m_out
+        elif p_drop > 0:
             keep = 1.0 - p_drop
             m_in = torch.empty_like(u_in).bernoulli_(keep).div_(keep)
             m_out = torch.empty_like(u_out).bernoulli_(keep).div_(keep)
@@ -309,6 +314,7 @@ class MGCN(nn.Module):
         self.conv1_extra = nn.ModuleList(
             [MGCNConv(params.gcn_out_dim, params.gcn_out_dim, num_relations * 2) for _ in range(extra)])
         self.edge_embeddings_extra = nn.ParameterList([table(params.gcn_out_dim) for _ in range(extra)])
+        self._optimizers = weakref.WeakSet()   # optimizers whose per-row state follows the tables' layout (attach_optimizer)
         self._edge_shard = None    # (csr, n0, n1) once dist.shard_model_tables has filled a partial table
         self._slot_csr = None      # per-edge tables are stored in this CSR's slot order (None = reference order)
         self._enc_cache = None
@@ -333,38 +339,63 @@ class MGCN(nn.Module):
                 state_dict[prefix + name] = t.index_select(0, inv.to(t.device))
         return state_dict
 
+    def attach_optimizer(self, optimizer):
+        """Tie `optimizer` to the per-edge tables' layout: from now on every layout switch (first use of a graph,
+        load_state_dict, a graph with permuted edge ids) moves the per-row optimizer state of those tables (Adam's
+        exp_avg / exp_avg_sq ...) with the rows. optimizer_state_dict / load_optimizer_state_dict and
+        utils.load_checkpoint(..., optimizer) attach for you; call it yourself right after building an optimizer that
+        takes neither route. Held weakly."""
+        self._optimizers.add(optimizer)
+        return optimizer
+
+    def _reorder_rows(self, index, data=True, only=None):
+        """rows[i] <- rows[index[i]] for the per-edge tables (`only`: a subset by name) and for the row-shaped state the
+        attached optimizers keep for them; `data=False` leaves the parameters themselves alone (they were just loaded)."""
+        with torch.no_grad():
+            for name, p in self._edge_tables():
+                if only is not None and name not in only:
+                    continue
+                idx = index.to(p.device)
+                if data:
+                    p.data.copy_(p.data.index_select(0, idx))
+                for opt in list(self._optimizers):
+                    st = opt.state.get(p)
+                    if not st:
+                        continue
+                    for k, v in list(st.items()):
+                        if torch.is_tensor(v) and v.dim() > 0 and v.size(0) == p.size(0):
+                            st[k] = v.index_select(0, idx.to(v.device)).contiguous()
+
     @staticmethod
     def _loaded_reference_order(module, incompatible_keys):
-        # the tables that were just loaded are in reference order; one that was MISSING from the state dict
-        # (strict=False) still holds its slot-ordered data: bring it back to reference order before forgetting the layout
+        # the tables that were just loaded are in reference order (their optimizer state, if any, still in slot order);
+        # one that was MISSING from the state dict (strict=False) still holds its slot-ordered data: bring everything
+        # back to reference order before forgetting the layout
         if module._slot_csr is not None:
             missing = set(incompatible_keys.missing_keys)
-            with torch.no_grad():
-                for name, p in module._edge_tables():
-                    if name in missing:
-                        p.data.copy_(p.data.index_select(0, module._slot_csr.inv_perm.to(p.device)))
+            inv = module._slot_csr.inv_perm
+            names = [name for name, _ in module._edge_tables()]
+            module._reorder_rows(inv, data=True, only=[n for n in names if n in missing])
+            module._reorder_rows(inv, data=False, only=[n for n in names if n not in missing])
         module._slot_csr = None
         module._enc_cache = None
 
     def _use_slot_order(self, csr):
         """Lay the per-edge tables out in `csr`'s slot order, in place, once per graph: the aggregation kernel
-        then STREAMS them (58 % of a WN18RR layer's bytes) instead of gathering rows by edge id. Gradients and
-        optimizer state follow the same order; state_dict() converts back (reference order on disk)."""
+        then STREAMS them (58 % of a WN18RR layer's bytes) instead of gathering rows by edge id. Gradients and the
+        state of attached optimizers follow the same order; state_dict() converts back (reference order on disk)."""
         if self._slot_csr is csr:
             return
-        with torch.no_grad():
-            for _, p in self._edge_tables():
-                t = p.data if self._slot_csr is None else p.data.index_select(0, self._slot_csr.inv_perm)
-                p.data.copy_(t.index_select(0, csr.perm))
+        if self._slot_csr is not None:
+            self._reorder_rows(self._slot_csr.inv_perm)
+        self._reorder_rows(csr.perm)
         self._slot_csr = csr
 
     def _use_reference_order(self):
-        """Undo _use_slot_order: the per-edge tables back in reference edge-id order, in place."""
+        """Undo _use_slot_order: the per-edge tables (and attached optimizer state) back in reference edge-id order."""
         if self._slot_csr is None:
             return
-        with torch.no_grad():
-            for _, p in self._edge_tables():
-                p.data.copy_(p.data.index_select(0, self._slot_csr.inv_perm.to(p.device)))
+        self._reorder_rows(self._slot_csr.inv_perm)
         self._slot_csr = None
         self._enc_cache = None
 
@@ -375,6 +406,7 @@ class MGCN(nn.Module):
         """optimizer.state_dict() with the per-row state of the per-edge tables (Adam's exp_avg / exp_avg_sq follow the
         parameter's in-place slot order) brought back to REFERENCE edge-id order — what main.py:160 should store as
         'optim_dict' so that the file does not depend on this build's slot layout (hub threshold, chunking)."""
+        self.attach_optimizer(optimizer)
         sd = optimizer.state_dict()
         if self._slot_csr is None:
             return sd
@@ -391,8 +423,10 @@ class MGCN(nn.Module):
 
     def load_optimizer_state_dict(self, optimizer, state_dict):
         """Inverse of optimizer_state_dict: load a reference-order 'optim_dict' (also one written by the reference itself)
-        and lay the per-edge tables' state out in the current slot order."""
+        and lay the per-edge tables' state out in the current slot order. The optimizer stays attached, so the state keeps
+        following the rows when the layout changes later (e.g. the first encode() after a resume)."""
         optimizer.load_state_dict(state_dict)
+        self.attach_optimizer(optimizer)
         if self._slot_csr is None:
             return
         ids, perm = self._edge_table_ids(), self._slot_csr.perm

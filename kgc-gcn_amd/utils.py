@@ -90,7 +90,10 @@ def _numpy_scalar_globals():
     Allow-listing exactly these keeps torch.load on the no-code (weights_only) path."""
     import numpy as np
     core = getattr(np, '_core', None) or np.core
-    return [core.multiarray.scalar, np.dtype, type(np.dtype('float64'))]
+    scalar = core.multiarray.scalar
+    # the constructor is pickled under the module path of the numpy that WROTE the file: numpy.core (1.x) or numpy._core (2.x)
+    return [(scalar, 'numpy.core.multiarray.scalar'), (scalar, 'numpy._core.multiarray.scalar'), np.dtype,
+            type(np.dtype('float64'))]
 
 
 def load_checkpoint(checkpoint, model, optimizer=None):
@@ -100,6 +103,11 @@ def load_checkpoint(checkpoint, model, optimizer=None):
         ckpt = torch.load(checkpoint, map_location='cpu', weights_only=True)
     model.load_state_dict(ckpt['state_dict'])
     if optimizer is not None:
-        optimizer.load_state_dict(ckpt['optim_dict'])
+        # 'optim_dict' is in reference edge order: the model lays it out with its tables and keeps the two tied
+        loader = getattr(model, 'load_optimizer_state_dict', None)
+        if loader is not None:
+            loader(optimizer, ckpt['optim_dict'])
+        else:
+            optimizer.load_state_dict(ckpt['optim_dict'])
     measure = ckpt.get('measure', None)
     return float(measure) if measure is not None else None

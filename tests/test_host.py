@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(pkg):
     handle = ctypes.CDLL(pkg._native.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert pkg._native.lib().mgcn_abi_version() == 2
+    assert pkg._native.lib().mgcn_abi_version() == 3
 
 
 @pytest.mark.parametrize('case', ALL_CASES)
@@ -474,14 +474,14 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         ('mgcn_aggregate_bwd', (4, 2, 0, 3, N, N, N, N, N, N, 0, N, N, N, 4, N, N, N, 8, N, N, N, N, 0, N), 'bad sizes'),
         ('mgcn_dense_bn_tanh_fwd', (4, 4, 4, N, 12, N, N, N, N, N, N, 1e-5, N, 4, N), 'null pointer'),
         ('mgcn_layer_fwd_fused', (4, 2, 4, 4, 3, N, N, N, 4, N, N, N, 1, N, N, N, N, N, N, N, 1e-5, N, 4, 2, 1, 0, 0, 0, N, N, 0,
-                                  0, N, N, N, N), 'bad node range'),
+                                  0, N, N, N, 0, N), 'bad node range'),
         ('mgcn_score_fwd', (4, 8, 4, N, 4, N, 4, N, N, 8, N), 'null pointer'),
         ('mgcn_score_rank', (4, 8, 0, 4, N, 4, N, 4, N, N, N, N, 0, N, 0, N, N), 'null pointer'),
         ('mgcn_filter_mask', (4, N, 0, N, N, N, 0, 8, N, 1, N), 'null pointer'),
         ('mgcn_label_rows', (4, N, 0, N, N, N, 0, 8, 1.0, 0.0, N, 4, N), 'leading|sizes|null'),
         ('mgcn_score_bce_fwd', (4, 8, 4, N, 4, N, 4, N, N, 1, 1.0, 0.0, 0.1, N, 4, N, N), 'null pointer'),
         ('mgcn_matmul_f32', (4, 4, 4, N, 4, N, 4, N, 4, N), 'null pointer'),
-        ('mgcn_pack_weights', (4, 4, N, N, 0, N), 'bad arguments'),
+        ('mgcn_pack_weights', (4, 4, N, N, 0, 0, N), 'bad arguments'),
     ]
     for name, args, pattern in cases:
         rc = getattr(lib, name)(*args)
@@ -489,8 +489,8 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         assert rc == 1, (name, rc, msg)
         assert re.search(pattern, msg), (name, msg)
     # second-generation fused layer: 3 modes x 4 k-blocks of 32 (100 -> 128 columns) x 13 column tiles x 3 bf16 pieces x 1 KiB
-    assert lib.mgcn_packed_weights_bytes(100, 200) == 3 * 4 * 13 * 3 * 64 * 16
-    assert lib.mgcn_packed_weights_bytes(200, 200) == 3 * 7 * 13 * 3 * 64 * 16   # 128 + 72 columns: 4 + 3 k-blocks
+    assert lib.mgcn_packed_weights_bytes(100, 200, 0) == 3 * 4 * 13 * 3 * 64 * 16
+    assert lib.mgcn_packed_weights_bytes(200, 200, 0) == 3 * 7 * 13 * 3 * 64 * 16   # ceil(200 / 32) = 7 k-blocks per mode
     assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
     assert lib.mgcn_score_bce_partials(128, 40943) == 1280
 
@@ -509,3 +509,85 @@ def test_chunkwise_xavier_table_rows(pkg):
     assert torch.equal(pkg.dist.xavier_rows(ids, rows, dim, seed, 'cpu', chunk=128), full.index_select(0, ids))
     assert not torch.equal(pkg.dist.xavier_rows(ids, rows, dim, seed + 1, 'cpu', chunk=128), full.index_select(0, ids))
     assert pkg.dist.xavier_rows(torch.zeros(0, dtype=torch.int64), rows, dim, seed, 'cpu').shape == (0, dim)
+
+
+def test_checkpoint_written_under_numpy_1_loads(pkg, tmp_path):
+    """a checkpoint the reference wrote under numpy 1.x pickles `measure` through
+    numpy.core.multiarray.scalar (numpy 2.x: numpy._core...). Both spellings are on the weights-only allow-list:
+    rewrite the GLOBAL in data.pkl to the other spelling and load through the no-code loader."""
+    import zipfile
+    g = golden('toy_small')
+    dl, params = _loader(pkg, g)
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    src = os.path.join(tmp_path, 'np2.ckpt')
+    torch.save({'state_dict': model.state_dict(), 'optim_dict': {}, 'measure': np.round(np.float64(0.25), 5)}, src)
+    for old, new in ((b'numpy._core.multiarray', b'numpy.core.multiarray'), (b'numpy.core.multiarray', b'numpy._core.multiarray')):
+        dst = os.path.join(tmp_path, 'other.ckpt')
+        hits = 0
+        with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, 'w', zipfile.ZIP_STORED) as zout:
+            for item in zin.infolist():
+                data = zin.read(item.filename)
+                if item.filename.endswith('data.pkl'):
+                    hits += data.count(old)
+                    data = data.replace(old, new)
+                zout.writestr(item.filename, data)
+        if not hits:
+            continue                      # this numpy writes the other spelling
+        fresh = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+        assert pkg.utils.load_checkpoint(dst, fresh) == 0.25
+        return
+    raise AssertionError('data.pkl names neither numpy.core nor numpy._core')
+
+
+def test_resumed_optimizer_state_follows_the_table_rows(pkg, tmp_path):
+    """resume = load_state_dict, then utils.load_checkpoint's optimizer load, then the first
+    encode() lays the tables out in slot order. The Adam moments must move with the rows: one step after the resume
+    equals the same step of the uninterrupted run, bit for bit, under a DIFFERENT slot layout."""
+    import types
+    g = golden('toy_small')
+    dl, params = _loader(pkg, g)
+
+    def fake_csr(seed):
+        perm = torch.randperm(2 * dl.num_edge, generator=torch.Generator().manual_seed(seed))
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        return types.SimpleNamespace(perm=perm, inv_perm=inv)
+
+    def step(model, opt, csr, seed):
+        # the same reference-order gradient for every parameter, laid out like the tables
+        gen = torch.Generator().manual_seed(seed)
+        tables = {id(p) for _, p in model._edge_tables()}
+        for p in model.parameters():
+            gr = torch.randn(p.shape, generator=gen)
+            p.grad = gr.index_select(0, csr.perm) if id(p) in tables else gr
+        opt.step()
+
+    model = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    model.load_state_dict(g.state_dict())
+    opt = model.attach_optimizer(torch.optim.Adam(model.parameters(), lr=1e-2))
+    csr_a = fake_csr(1)
+    model._use_slot_order(csr_a)
+    step(model, opt, csr_a, 10)
+    step(model, opt, csr_a, 11)
+    pkg.utils.save_checkpoint({'state_dict': model.state_dict(), 'optim_dict': model.optimizer_state_dict(opt), 'measure': 0.5},
+                              False, str(tmp_path))
+    step(model, opt, csr_a, 12)                       # the uninterrupted run's next step
+
+    resumed = pkg.MGCN(dl.num_entity, dl.num_relation, dl.num_edge, params)
+    ropt = torch.optim.Adam(resumed.parameters(), lr=1e-2)
+    pkg.utils.load_checkpoint(os.path.join(tmp_path, 'last.ckpt'), resumed, ropt)      # slot layout unknown at this point
+    csr_b = fake_csr(2)
+    resumed._use_slot_order(csr_b)                    # what the first encode() does
+    step(resumed, ropt, csr_b, 12)
+    want, got = model.state_dict(), resumed.state_dict()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    # a layout switch in mid-training (a graph with permuted edge ids -> reference order) keeps them tied too
+    resumed._use_reference_order()
+    model._use_slot_order(csr_b)
+    ident = types.SimpleNamespace(perm=torch.arange(2 * dl.num_edge), inv_perm=torch.arange(2 * dl.num_edge))
+    step(resumed, ropt, ident, 13)
+    step(model, opt, csr_b, 13)
+    want, got = model.state_dict(), resumed.state_dict()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
