@@ -216,9 +216,8 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
                          int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, const int32_t *hubinfo_dev,
                          const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
                          const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream);
-int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, int32_t tune,
-                      void *stream);
-size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out, int32_t tune);
+int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
+size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 
 /* ---------------------------------------------------------------------------------------------
  * (4t) The layer's epilogue in TRAINING mode and its backward (model.py:103-106 under .train(), driven by main.py:61-66):

@@ -31,8 +31,8 @@ _SIGNATURES = {
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
                                             _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
-    'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _i32, _ptr]),
-    'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32, _i32]),
+    'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_bn_tanh_train_workspace': (ctypes.c_size_t, [_i64, _i32]),
     'mgcn_bn_tanh_train_fwd': (ctypes.c_int, [_i64, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr,
@@ -273,15 +273,15 @@ def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, o
     return out
 
 
-# `tune` argument of the fused layer entry points (include/mgcn_hip.h): 0 = automatic geometry. Read ONCE at import,
-# for A/B tools only: bits 0-3 row tiles per tile, 4-7 LDS images, 8-9 relation table in LDS, 10-11 kernel generation.
+# `tune` argument of mgcn_layer_fwd_fused (include/mgcn_hip.h): 0 = automatic geometry. Read ONCE at import, for A/B tools
+# only: bits 0-3 row tiles per tile, 4-7 staging buffers, 8-9 relation table in LDS.
 FUSED_TUNE = int(os.environ.get('MGCN_FUSED_TUNE', '0'), 0)
 FUSED_ENABLED = os.environ.get('MGCN_FUSED', '1') != '0'
 
 
 def fused_supported(d_in, d_out):
     """Shapes the one-launch layer kernel handles (else: aggregate_fwd + dense_bn_tanh_fwd)."""
-    return FUSED_ENABLED and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0 and d_out <= 208
+    return FUSED_ENABLED and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0 and d_out <= 512
 
 
 def pack_weights(w_cat, out=None):
@@ -289,14 +289,14 @@ def pack_weights(w_cat, out=None):
     D, O = w_cat.size(0) // 3, w_cat.size(1)
     if w_cat.dim() != 2 or w_cat.size(0) != 3 * D or not w_cat.is_contiguous():
         raise NativeError('pack_weights: w_cat must be contiguous (3D, O)')
-    nbytes = lib().mgcn_packed_weights_bytes(D, O, FUSED_TUNE)
+    nbytes = lib().mgcn_packed_weights_bytes(D, O)
     if out is None:
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_cat.device)
     if out.numel() * 4 < nbytes:
         raise NativeError('pack_weights: out too small')
     _same_device(w_cat, out)
     _check(lib().mgcn_pack_weights(D, O, _dev(w_cat, torch.float32, 'w_cat'), _dev(out, torch.float32, 'wp'),
-                                   out.numel() * 4, FUSED_TUNE, _stream(w_cat)), 'mgcn_pack_weights')
+                                   out.numel() * 4, _stream(w_cat)), 'mgcn_pack_weights')
     return out
 
 
@@ -323,7 +323,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         if not ee_in_slot_order or tuple(ee.shape) != (sum(rows), D) or not ee.is_contiguous() or \
                 ee_sub != csr.shard_ee_sub(n0, n1):
             raise NativeError('layer_fwd_fused: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
-    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O, FUSED_TUNE):
+    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
         raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:

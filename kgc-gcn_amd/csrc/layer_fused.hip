@@ -1,6 +1,6 @@
 // Fused layer forward (eval) — C-ABI entry points: mgcn_pack_weights / mgcn_packed_weights_bytes /
 // mgcn_layer_fwd_fused (include/mgcn_hip.h (2)+(4)); replaces model.py:29-30, 99-107, 111-118 in one launch.
-// The kernels are layer_fused3.hip (third generation) and, for A/B runs, layer_fused2.hip.
+// The kernel is layer_fused3.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -8,24 +8,16 @@
 #include "mgcn_common.h"
 
 
-namespace {
-// tune bits 10-11: kernel generation for A/B runs (0 = the default: 3; 2 = layer_fused2.hip)
-constexpr int DEFAULT_GEN = 2;
-int gen_of(int32_t tune) { const int g = (tune >> 10) & 3; return g ? g : DEFAULT_GEN; }
-}  // namespace
-
-extern "C" size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out, int32_t tune) {
-  if (gen_of(tune) == 3) return mgcn::fused3_packed_bytes(dim_in, dim_out);
-  return mgcn::fused2_packed_bytes(dim_in, dim_out);
+extern "C" size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out) {
+  return mgcn::fused3_packed_bytes(dim_in, dim_out);
 }
 
 extern "C" int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes,
-                                 int32_t tune, void *stream) {
+                                 void *stream) {
   MGCN_REQUIRE(dim_in > 0 && dim_out > 0 && w_dev && wp_dev, "pack_weights: bad arguments");
-  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes(dim_in, dim_out, tune) && mgcn::aligned16(wp_dev),
+  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes(dim_in, dim_out) && mgcn::aligned16(wp_dev),
                "pack_weights: packed buffer too small or misaligned");
-  if (gen_of(tune) == 3) return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
-  return mgcn::fused2_pack(dim_in, dim_out, w_dev, wp_dev, stream);
+  return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
 }
 
 extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
@@ -51,9 +43,9 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   const bool aligned = mgcn::aligned16(x_dev) && mgcn::aligned16(rel_dev) && mgcn::aligned16(loop_rel_dev) &&
                        mgcn::aligned16(loop_edge_dev) && (!ee_dev || mgcn::aligned16(ee_dev)) &&
                        mgcn::aligned16(out_dev) && mgcn::aligned16(wp_dev) && ldx % 4 == 0 && ldo % 4 == 0;
-  if (!aligned || !(gen_of(tune) == 3 ? mgcn::fused3_takes(dim_in, dim_out) : mgcn::fused2_takes(dim_in, dim_out)) || !ee_dev || !ee_in_slot_order || ldx >= (int64_t(1) << 31))
+  if (!aligned || !mgcn::fused3_takes(dim_in, dim_out) || !ee_dev || !ee_in_slot_order || ldx >= (int64_t(1) << 31))
     return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: needs 16-byte aligned operands, a per-edge table in slot order, "
-                      "D %% 4 == 0, D <= 1024, O %% 4 == 0, O <= 208 (got D=%d O=%d)", dim_in, dim_out);
+                      "D %% 4 == 0, D <= 1024, O %% 4 == 0, O <= 512 (got D=%d O=%d)", dim_in, dim_out);
   const int64_t num_chunks = chunk_end - chunk_begin;
   MGCN_REQUIRE(chunk_begin >= 0 && num_chunks >= 0 && chunk_end < (int64_t(1) << 31) &&
                    (num_chunks == 0 || (hubinfo_dev && chunks_dev && partial_dev && mgcn::aligned16(partial_dev))),
@@ -67,15 +59,9 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                            partial_dev, stream))
       return rc;
   }
-  if (gen_of(tune) == 3)
-    return mgcn::fused3_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
+  return mgcn::fused3_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
                                num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
                                want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, tune, stream);
-  return mgcn::fused2_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
-                             loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
-                             bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
-                             num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
-                             want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, stream);
 }

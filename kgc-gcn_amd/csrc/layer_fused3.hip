@@ -11,13 +11,16 @@
 //               rows are dealt to the groups by work; a group sums its rows' slots in slot order (the sums of
 //               agg_fwd_kernel) and writes each finished row, split exactly into three bf16 pieces, to an LDS image.
 //   waves 0-7   MULTIPLY  v_mfma_f32_16x16x32_bf16 on the six significant products of the split operands (f32-faithful:
-//               see layer_fused2.hip / DESIGN.md), weights pre-split and pre-packed, streamed from L2 one k-block ahead;
+//               see split3 below / DESIGN.md), weights pre-split and pre-packed, streamed from L2 one k-block ahead;
 //               epilogue tanh(acc * scale + shift) (model.py:103-106) on the accumulators.
-// Stage = (mode, pass of 128 * NCH columns). Images are EXACTLY as wide as the pass (ceil(width / 8) 16-byte chunk
-// columns, not 128 / 256 columns): a 100-wide image of 80 rows is 50 KB, so THREE fit beside the relation table.
-// The roles are coupled by a ring of nimg images with two LDS counters each (rows written / rows consumed), not by a
-// workgroup barrier: the gather runs up to nimg - 1 stages ahead of the multiply, a fast wave never waits for a slow
-// one of its own role, and a tile's epilogue overlaps the next tile's gather. Every spin is bounded.
+// Stage = (mode, pass of 128 * NCH columns). The gather role is the launch's critical path (its waves run ~15 cycles per
+// instruction beside the MFMA waves' LDS traffic), the multiply role has slack: so the gather only STORES finished f32
+// rows into a staging buffer (one ds_write_b128 per lane and row), and the MFMA waves split each staged tile into the
+// three bf16 pieces (a branch-free pass, 2 rows per wave-instruction) before multiplying it. Buffers are exactly as
+// wide as the pass (ceil(width / 8) 16-byte chunk columns). The roles are coupled by a ring of `nimg` staging buffers
+// with two LDS counters each (rows staged / tile converted), not by a workgroup barrier: the gather runs up to nimg
+// stages ahead, a fast wave never waits for a slow one of the other role, a tile's epilogue overlaps the next tile's
+// gather. The MFMA waves order their own convert / multiply phases with two more counters. Every spin is bounded.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -37,7 +40,7 @@ struct Args3 {
   const int32_t *rowptr;
   const int4 *rec;
   const float *x, *rel, *loop_rel, *ee, *loop_edge;
-  const u32x4 *wp;        // packed weights [G][NT][3][64] (8 bf16 per lane), layer_fused2.hip pack2_kernel
+  const u32x4 *wp;        // packed weights [G][NT][3][64] (8 bf16 per lane), pack3_kernel
   const float *bias, *bn_mean, *bn_var, *bn_gamma, *bn_beta;
   float *out;
   int64_t ldx, ldo;
@@ -59,11 +62,13 @@ struct Args3 {
 };
 #ifdef MGCN_DIAG
 #define DIAG_NOW() __builtin_readcyclecounter()
+#define DIAG_LAP(acc) do { const unsigned long long t_ = DIAG_NOW(); acc += t_ - t_last; t_last = t_; } while (0)
 #else
 #define DIAG_NOW() 0ull
+#define DIAG_LAP(acc) do {} while (0)
 #endif
 
-__device__ __forceinline__ float tanh3_(float v) {   // exp2 + rcp, 7 VALU per value (as layer_fused2.hip)
+__device__ __forceinline__ float tanh3_(float v) {   // exp2 + rcp, 7 VALU per value
   const float t = __builtin_amdgcn_exp2f(fabsf(v) * -2.885390081777927f);
   return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
 }
@@ -85,8 +90,10 @@ __device__ __forceinline__ float4 f4axpy(float4 s, float4 m, float w) {
   return make_float4(s.x + m.x * w, s.y + m.y * w, s.z + m.z * w, s.w + m.w * w);
 }
 
-// LDS counters: [0..3] rows-written per image, [4..7] rows-consumed per image, [8] one-time tables ready
+// LDS counters: [0..3] rows staged per staging buffer, [4..7] buffer converted (free again), [8] one-time tables ready,
+// [9] MFMA waves that have converted their share of the current stage, [10] MFMA waves done multiplying a stage
 __device__ __forceinline__ void wait_ge_(const uint32_t *c, uint32_t need) {
+#pragma nounroll
   for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
     const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (v >= need) break;
@@ -107,9 +114,11 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   constexpr int CH = 32;                // slots served by one record chunk (lane i: slot cbase + i)
   constexpr int OP = NT * 16;           // padded output width
   extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-  const int piece = p.ncc * BM * 16;    // bytes of one bf16 piece of an image: [chunk column][row][16 B]
-  const int buf = 3 * piece;
-  uint32_t *cnt = reinterpret_cast<uint32_t *>(lds3 + p.nimg * buf);
+  const int piece = p.ncc * BM * 16;    // bytes of one bf16 piece of the image: [chunk column][row][16 B]
+  const int rowb = p.ncc * 32;          // bytes of one staged f32 row (8 floats per chunk column)
+  const int sbuf = BM * rowb;           // one staging buffer: [row][column] f32
+  unsigned char *stg0 = lds3 + 3 * piece;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(stg0 + p.nimg * sbuf);
   float *epi = reinterpret_cast<float *>(cnt + 16);   // [scale | shift] x OP: the epilogue as one fma per value
   float *rel_lds = epi + 2 * OP;                      // [rel_rows - 1][D] when RELLDS
 
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   __syncthreads();   // the only workgroup barrier: nothing is in flight yet
 #ifdef MGCN_DIAG
   const unsigned long long t_begin = DIAG_NOW();
-  unsigned long long t_wait = 0, n_wait = 0, t_load = 0, n_load = 0;
+  unsigned long long t_wait = 0, n_wait = 0, t_load = 0, n_load = 0, t_last = t_begin, t_a = 0, t_b = 0, t_d = 0, t_o = 0;
   auto wait_ge = [&](const uint32_t *c, uint32_t need) __attribute__((always_inline)) {
     const unsigned long long t0 = DIAG_NOW();
     wait_ge_(c, need);
@@ -136,8 +145,8 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   };
   auto diag_end = [&]() __attribute__((always_inline)) {
     if (p.diag && lane == 0) {
-      unsigned long long *d = p.diag + (int64_t(bid) * 16 + wave) * 4;
-      d[0] = DIAG_NOW() - t_begin; d[1] = t_wait; d[2] = wave >= 8 ? t_load : n_wait; d[3] = wave >= 8 ? n_load : t_begin;
+      unsigned long long *d = p.diag + (int64_t(bid) * 16 + wave) * 8;
+      d[0] = DIAG_NOW() - t_begin; d[1] = t_wait; d[2] = t_load; d[3] = n_load; d[4] = t_a; d[5] = t_b; d[6] = t_d; d[7] = t_o;
     }
   };
 #else
@@ -150,36 +159,25 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     const int gtid = tid - 512;
     const int grp = gtid >> 5, lig = gtid & 31;
     const int glane0 = lane & 32;
-    const int qcol = lig >> 1, frot = (qcol >> 1) & 7;     // (chunk column 16 j + qcol rotates like qcol)
-    const int wbase = qcol * BM * 16 + (lig & 1) * 8;
+    const int qcol = lig >> 1;
     const uint32_t ldx32 = uint32_t(p.ldx), d32 = uint32_t(p.d);
     bool wr[NCH];                                           // this lane's chunk column j exists in the image
 #pragma unroll
     for (int j = 0; j < NCH; ++j) wr[j] = 16 * j + qcol < p.ncc;
 
-    auto write_row = [&](unsigned char *img, int row, const float4 (&v)[NCH], const bool (&ok)[NCH]) __attribute__((always_inline)) {
-      const int rr = ((row & ~15) + (((row & 15) + frot) & 15)) * 16;
+    auto write_row = [&](unsigned char *stg, int row, const float4 (&v)[NCH], const bool (&ok)[NCH]) __attribute__((always_inline)) {
+      unsigned char *dst = stg + row * rowb + lig * 16;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        if (wr[j]) {
-          uint32_t h[4], m[4], l[4];
-          split3(ok[j] ? v[j].x : 0.f, h[0], m[0], l[0]);
-          split3(ok[j] ? v[j].y : 0.f, h[1], m[1], l[1]);
-          split3(ok[j] ? v[j].z : 0.f, h[2], m[2], l[2]);
-          split3(ok[j] ? v[j].w : 0.f, h[3], m[3], l[3]);
-          unsigned char *dst = img + wbase + j * (256 * BM) + rr;
-          *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-          *reinterpret_cast<uint2 *>(dst + piece) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-          *reinterpret_cast<uint2 *>(dst + 2 * piece) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
-        }
+        if (wr[j]) *reinterpret_cast<float4 *>(dst + j * 512) = ok[j] ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     // ring position of the next stage this wave fills
     int s_img = 0;
     uint32_t s_round = 0;
     auto acquire = [&]() __attribute__((always_inline)) {
-      if (s_round > 0) wait_ge(cnt + 4 + s_img, 8u * s_round);   // all 8 MFMA waves are done with the image's last use
-      return lds3 + s_img * buf;
+      if (s_round > 0) wait_ge(cnt + 4 + s_img, 8u * s_round);   // all 8 MFMA waves have converted the buffer's last tile
+      return stg0 + s_img * sbuf;
     };
     auto publish = [&]() __attribute__((always_inline)) {
       signal_add(cnt + s_img, lane);
@@ -317,6 +315,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
             };
             int cbase = beg;                                   // first slot of the record chunk held in myrec
             for (int s = beg; s < end; s += UB) {
+              DIAG_LAP(t_o);
               if (s >= cbase + CH) {                           // group-uniform: next record chunk of a long range
                 cbase += CH;
                 myrec = rec_chunk(cbase, end);
@@ -340,18 +339,17 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
                   ev[u][j] = *reinterpret_cast<const float4 *>(p.ee + coff[j] + uint64_t(erow) * d32);
                 }
               }
+              DIAG_LAP(t_a);
               if (!next_recs_issued) {   // behind this batch's row loads: the next (tile, mode)'s partition and records
                 next_recs_issued = true;
                 prefetch_next();
               }
+              DIAG_LAP(t_b);
 #ifdef MGCN_DIAG
-              {
-                const unsigned long long t0 = DIAG_NOW();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                t_load += DIAG_NOW() - t0;
-                ++n_load;
-              }
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              ++n_load;
 #endif
+              DIAG_LAP(t_load);
 #pragma unroll
               for (int u = 0; u < UB; ++u) {
                 if (s + u < end) {
@@ -367,6 +365,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
                   }
                 }
               }
+              DIAG_LAP(t_d);
             }
             if (!next_recs_issued) {
               next_recs_issued = true;
@@ -454,59 +453,35 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     // ------------------------------------------------------------------------------------------ MULTIPLY
     auto multiply = [&](auto Hc) __attribute__((always_inline)) {
     constexpr int H = decltype(Hc)::value;
-    // Column group sg = wave & 3 (the SIMD) owns NT/4 column tiles; its two waves split them: half H = 0 takes the
-    // first ceil, half H = 1 the rest plus the group's share of the NT % 4 left-over column tiles, dealt as single
-    // (column tile, row tile) units. Two MFMA waves per SIMD: one's fragment waits are the other's issue slots.
-    constexpr int QALL = NT / 4, R = NT % 4;
-    constexpr int QA = (QALL + 1) / 2;
-    constexpr int Q = H == 0 ? QA : QALL - QA;       // this wave's whole column tiles
-    constexpr int QF = Q > 0 ? Q : 1;
-    constexpr int NX = H == 1 ? R * NRT : 0;         // single units shared out round-robin over the four H = 1 waves
-    constexpr int XE = (NX + 3) / 4;                 // ... at most XE per wave
-    constexpr int XF = XE > 0 ? XE : 1;
-    constexpr int XW = (R == 1) ? 1 : XF;            // weight fragments for them (R == 1: all in one column tile)
+    static_assert(NT == 13 || NT == 32, "13 column tiles (O <= 208) or 32 (O <= 512)");
+    // The SIMD's two MFMA waves (w = wave & 3, half H) share its column tiles. NT = 13: tiles 3w, 3w + 1 (H = 0) or 3w + 2
+    // and a share of the 13th tile, dealt as single (column tile, row tile) units, row tile 4 j + w (H = 1). NT = 32:
+    // tiles 8w + 4H + e, e = 0..3. A wave's k-block is E ENTRIES of one column tile each: the weight fragments of an
+    // entry (three bf16 pieces, 12 registers) are loaded one entry ahead, so only two triples are live — which leaves
+    // registers to read the row fragments of row tile rt + 1 before the MFMAs of row tile rt.
+    constexpr int E = NT == 13 ? 2 : 4;
+    constexpr bool UNITS = NT == 13 && H == 1;         // the wave's last entry is single units of the 13th column tile
+    constexpr int XF = (NRT + 3) / 4;                  // ... at most XF of them
     const int w = wave & 3;
     const int r = lane & 15, gq = lane >> 4;
-    const int ct0 = w * QALL + (H == 0 ? 0 : QA);
-    int xct[XF], xrt[XF];
-    bool xok[XF];
+    auto ct_of = [&](int e) { return NT == 13 ? (e == 0 ? 3 * w + 2 * H : (H == 0 ? 3 * w + 1 : 12)) : 8 * w + 4 * H + e; };
+    int xrt[XF];
 #pragma unroll
-    for (int j = 0; j < XF; ++j) {
-      const int e = 4 * j + w;
-      xok[j] = XE > 0 && e < NX;
-      xct[j] = xok[j] ? 4 * QALL + e / NRT : 0;
-      xrt[j] = xok[j] ? e % NRT : -1;
-    }
-    const int G = p.G;
-    auto wload = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], int g) {
-      const u32x4 *base = p.wp + (int64_t(g) * NT) * 3 * 64 + lane;
+    for (int j = 0; j < XF; ++j) xrt[j] = (UNITS && 4 * j + w < NRT) ? 4 * j + w : NRT;   // NRT = no unit
+    auto wload = [&](u32x4 (&wv)[3], int g, int ct) __attribute__((always_inline)) {
+      const u32x4 *base = p.wp + ((int64_t(g) * NT + ct) * 3) * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < Q; ++t) {
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) wq[t][pc] = base[((ct0 + t) * 3 + pc) * 64];
-      }
-      if (XE > 0) {
-#pragma unroll
-        for (int j = 0; j < XW; ++j) {
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) wx[j][pc] = base[(xct[j] * 3 + pc) * 64];
-        }
-      }
+      for (int pc = 0; pc < 3; ++pc) wv[pc] = base[pc * 64];
     };
-    // Three NAMES for two live fragment sets: a k-block first issues the loads of the NEXT k-block into the set that
-    // died one k-block ago, then multiplies with its own (loaded one k-block earlier). G is a multiple of 3, so the
-    // rotation closes per tile with no conditional code between the k-blocks.
-    u32x4 wq0[QF][3], wx0[XW][3], wq1[QF][3], wx1[XW][3], wq2[QF][3], wx2[XW][3];
-
-    f32x4 acc[NRT][QF], accx[XF];
+    // Three NAMES for two live weight triples; entry i of the (3 k-block) loop body uses name i % 3 (G is a multiple of 3)
+    u32x4 wn[3][3];
+    f32x4 acc[E][NRT];
     auto zero_acc = [&]() {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
+      for (int e = 0; e < E; ++e) {
 #pragma unroll
-        for (int t = 0; t < QF; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < NRT; ++rt) acc[e][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int j = 0; j < XF; ++j) accx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     // lane holds out[row = 16 rt + r][16 ct + 4 gq .. + 3] (operands swapped: W is the MFMA's A operand)
     auto store_unit = [&](f32x4 a, int node, int col, const float4 &sc, const float4 &sh) {
@@ -518,22 +493,20 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     };
     auto epilogue = [&](int it_) {
       const int node0_ = row_lo + it_ * BM + r;
-      auto column_tile = [&](int ct, auto &&body) {
-        const int col = ct * 16 + 4 * gq;
-        if (col < p.o) body(col, *reinterpret_cast<const float4 *>(epi + col), *reinterpret_cast<const float4 *>(epi + OP + col));
-      };
 #pragma unroll
-      for (int t = 0; t < Q; ++t) {
-        column_tile(ct0 + t, [&](int col, const float4 &sc, const float4 &sh) {
+      for (int e = 0; e < E; ++e) {
+        const int col = ct_of(e) * 16 + 4 * gq;
+        if (col < p.o) {
+          const float4 sc = *reinterpret_cast<const float4 *>(epi + col), sh = *reinterpret_cast<const float4 *>(epi + OP + col);
+          if (UNITS && e == E - 1) {
 #pragma unroll
-          for (int rt = 0; rt < NRT; ++rt) store_unit(acc[rt][t], node0_ + rt * 16, col, sc, sh);
-        });
-      }
-      if (XE > 0) {
+            for (int j = 0; j < XF; ++j) {
+              if (xrt[j] < NRT) store_unit(acc[e][j], node0_ + xrt[j] * 16, col, sc, sh);
+            }
+          } else {
 #pragma unroll
-        for (int j = 0; j < XF; ++j) {
-          if (xok[j])
-            column_tile(xct[j], [&](int col, const float4 &sc, const float4 &sh) { store_unit(accx[j], node0_ + xrt[j] * 16, col, sc, sh); });
+            for (int rt = 0; rt < NRT; ++rt) store_unit(acc[e][rt], node0_ + rt * 16, col, sc, sh);
+          }
         }
       }
     };
@@ -556,7 +529,8 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
       const int mode_ = nmode == 0 ? 2 : nmode - 1;
       return mode_ * p.kbm + p.kbp * npass_ + nkb_;
     };
-    wload(wq0, wx0, gindex());
+    int gcur = gindex();
+    wload(wn[0], gcur, ct_of(0));
     advance_next();
     // once per workgroup, by the MFMA waves while the first stage is gathered: the epilogue's per-column vectors
     // (model.py:103-106 as one fma: tanh(acc * scale + shift)) and, when it fits, the relation table; published through
@@ -577,49 +551,120 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     }
     signal_add(cnt + 8, lane);
     int m_img = 0;
-    uint32_t m_round = 0;
+    uint32_t m_round = 0, m_stage = 0;
     int nrt_eff = NRT;
-    auto kblock = [&](u32x4 (&wq)[QF][3], u32x4 (&wx)[XW][3], u32x4 (&nq)[QF][3], u32x4 (&nx)[XW][3]) {
-      wload(nq, nx, gindex());           // the k-block after this one (wraps into the next tile: same weights)
-      advance_next();
-      const int nkb_c = (pass == npass - 1) ? p.nkb_last : p.kbp;
-      if (kb == 0) wait_ge(cnt + m_img, 8u * (m_round + 1));   // all 8 gather waves have written their rows of the image
-      int qc = 4 * kb + gq;
-      qc = qc < p.ncc ? qc : p.ncc - 1;   // columns past the image (last k-block): any finite value of the row, their weights are zero
-      const unsigned char *ap = lds3 + m_img * buf + (qc * BM + ((r + ((qc >> 1) & 7)) & 15)) * 16;
-      // the six products, small terms first: (w piece, a piece) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
+    // the six products, small terms first: (w piece, a piece) = (0,2) (2,0) (1,1) (0,1) (1,0) (0,0)
+    auto six = [&](f32x4 &accv, const u32x4 (&wv)[3], const bf16x8 (&a)[3]) __attribute__((always_inline)) {
       constexpr int WP[6] = {0, 2, 1, 0, 1, 0}, AP[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        if (Q > 0 && rt < nrt_eff) {
-          bf16x8 a[3];
+      for (int pr = 0; pr < 6; ++pr)
+        accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[WP[pr]]), a[AP[pr]], accv, 0, 0, 0);
+    };
+    auto frag = [&](bf16x8 (&a)[3], const unsigned char *ap, int rt) __attribute__((always_inline)) {
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * piece + rt * 256));
+      for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * piece + rt * 256));
+    };
+    auto tile_entry = [&](f32x4 (&accv)[NRT], const u32x4 (&wv)[3], const unsigned char *ap) __attribute__((always_inline)) {
+      if (nrt_eff == NRT) {   // every row tile exists: the fragments of row tile rt + 1 are read before the MFMAs of row tile rt
+        bf16x8 a[2][3];
+        frag(a[0], ap, 0);
 #pragma unroll
-          for (int pr = 0; pr < 6; ++pr) {
-#pragma unroll
-            for (int t = 0; t < Q; ++t)
-              acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wq[t][WP[pr]]), a[AP[pr]],
-                                                                   acc[rt][t], 0, 0, 0);
-          }
+        for (int rt = 0; rt < NRT; ++rt) {
+          if (rt + 1 < NRT) frag(a[(rt + 1) & 1], ap, rt + 1);
+          asm volatile("" ::: "memory");   // (the reads of row tile rt + 2 stay below: two fragment sets, not NRT)
+          six(accv[rt], wv, a[rt & 1]);
         }
-      }
-      if (XE > 0) {   // this wave's single units: their own fragment reads (row tile = a wave-uniform offset)
+      } else {
 #pragma unroll
-        for (int j = 0; j < XF; ++j) {
-          if (xok[j] && xrt[j] < nrt_eff) {
+        for (int rt = 0; rt < NRT; ++rt) {
+          if (rt < nrt_eff) {
             bf16x8 a[3];
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) a[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + pc * piece + xrt[j] * 256));
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
-              accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wx[XW == 1 ? 0 : j][WP[pr]]),
-                                                                a[AP[pr]], accx[j], 0, 0, 0);
+            frag(a, ap, rt);
+            six(accv[rt], wv, a);
           }
         }
       }
-      if (++kb == nkb_c) {               // the stage's image is consumed: hand it back to the gather
-        signal_add(cnt + 4 + m_img, lane);
+    };
+    auto unit_entry = [&](f32x4 (&accv)[NRT], const u32x4 (&wv)[3], const unsigned char *ap) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < XF; ++j) {       // (H = 1 only: single units of the 13th column tile)
+        if (xrt[j] < nrt_eff) {
+          bf16x8 a[3];
+          frag(a, ap, xrt[j]);
+          six(accv[j], wv, a);
+        }
+      }
+    };
+    auto kblock = [&](auto Kc) __attribute__((always_inline)) {
+      constexpr int K = decltype(Kc)::value;   // position of the k-block in the loop body (names of its entries: (K E + e) % 3)
+      wload(wn[(K * E + 1) % 3], gcur, ct_of(1));   // this k-block's second entry
+      const int nkb_c = (pass == npass - 1) ? p.nkb_last : p.kbp;
+      if (kb == 0) {
+        // the stage's tile: staged f32 rows -> the bf16 image. Wave w converts rows 8 i + w (NCH = 2) or 16 i + 2 w + (lane >> 5)
+        // (NCH = 1: two rows per wave-instruction); a lane splits one float4 exactly into three bf16 pieces.
+        DIAG_LAP(t_o);
+        wait_ge(cnt + m_img, 8u * (m_round + 1));          // all 8 gather waves have staged their rows
+        if (m_stage > 0) wait_ge(cnt + 10, 8u * m_stage);   // ... and all MFMA waves are done reading the previous image
+        const unsigned char *stg = stg0 + m_img * sbuf;
+        constexpr int RPI = NCH == 1 ? 16 : 8;               // rows per iteration of the 8 waves
+        const int ql = NCH == 1 ? (lane & 31) : lane;         // quad (float4) of the row
+        const int crow0 = NCH == 1 ? 2 * wave + (lane >> 5) : wave;
+        const bool qok = ql < 2 * p.ncc;
+        const int cc = ql >> 1;
+        const int coff = cc * BM * 16 + (ql & 1) * 8;
+        const int crot = (cc >> 1) & 7;
+        auto convert_row = [&](int row, const float4 &v) __attribute__((always_inline)) {
+          uint32_t h[4], m[4], l[4];
+          split3(v.x, h[0], m[0], l[0]);
+          split3(v.y, h[1], m[1], l[1]);
+          split3(v.z, h[2], m[2], l[2]);
+          split3(v.w, h[3], m[3], l[3]);
+          unsigned char *dst = lds3 + coff + ((row & ~15) + (((row & 15) + crot) & 15)) * 16;
+          *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+          *reinterpret_cast<uint2 *>(dst + piece) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+          *reinterpret_cast<uint2 *>(dst + 2 * piece) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+        };
+        if (qok) {
+          const unsigned char *src = stg + ql * 16;
+          const int rows = nrt_eff * 16;
+          int row = crow0;
+          for (; row + RPI < rows; row += 2 * RPI) {     // two rows per step: the reads first, then the arithmetic
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + row * rowb);
+            const float4 v1 = *reinterpret_cast<const float4 *>(src + (row + RPI) * rowb);
+            convert_row(row, v0);
+            convert_row(row + RPI, v1);
+          }
+          for (; row < rows; row += RPI) convert_row(row, *reinterpret_cast<const float4 *>(src + row * rowb));
+        }
+        signal_add(cnt + 4 + m_img, lane);                  // this wave's staged rows are consumed
+        signal_add(cnt + 9, lane);
+        DIAG_LAP(t_a);
+        wait_ge(cnt + 9, 8u * (m_stage + 1));                // the whole image is written
+        DIAG_LAP(t_b);
+      }
+      int qc = 4 * kb + gq;
+      qc = qc < p.ncc ? qc : p.ncc - 1;   // columns past the image (last k-block): any finite value of the row, their weights are zero
+      const unsigned char *ap = lds3 + (qc * BM + ((r + ((qc >> 1) & 7)) & 15)) * 16;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (e > 0) {                       // the entry after this one: the next column tile, or the next k-block's first
+          if (e + 1 < E) {
+            wload(wn[(K * E + e + 1) % 3], gcur, ct_of(e + 1));
+          } else {
+            gcur = gindex();               // (wraps into the next tile: same weights)
+            wload(wn[(K * E + E) % 3], gcur, ct_of(0));
+            advance_next();
+          }
+        }
+        if (NT == 13 || ct_of(e) * 16 < p.o) {    // (NT = 32: column tiles past the output width are skipped)
+          if (UNITS && e == E - 1) unit_entry(acc[e], wn[(K * E + e) % 3], ap);
+          else tile_entry(acc[e], wn[(K * E + e) % 3], ap);
+        }
+      }
+      if (++kb == nkb_c) {               // this wave is done reading the image
+        DIAG_LAP(t_d);
+        signal_add(cnt + 10, lane);
+        ++m_stage;
         if (++m_img == nimg) { m_img = 0; ++m_round; }
         kb = 0;
         if (++pass == npass) pass = 0;
@@ -632,12 +677,12 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
         const int left = myrows - it * BM;
         nrt_eff = left < BM ? (left + 15) >> 4 : NRT;
       }
-      for (int g0 = 0; g0 < G; g0 += 3) {
-        kblock(wq0, wx0, wq1, wx1);
-        kblock(wq1, wx1, wq2, wx2);
-        kblock(wq2, wx2, wq0, wx0);
+      for (int g0 = 0; g0 < p.G; g0 += 3) {
+        kblock(std::integral_constant<int, 0>{});
+        kblock(std::integral_constant<int, 1>{});
+        kblock(std::integral_constant<int, 2>{});
       }
-      epilogue(it);   // the tile's images are already back with the gather, which is one or two stages ahead
+      epilogue(it);   // overlaps the gather, which is up to nimg stages ahead
     }
     diag_end();
     };
@@ -646,7 +691,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   }
 }
 
-constexpr int NT3 = 13;   // column tiles of the multiply role: O <= 208 (narrower outputs ride along zero-padded)
+int pick_nt3(int o) { return o <= 208 ? 13 : 32; }   // column tiles of the multiply role (narrower outputs ride along zero-padded)
 
 // wp[((g * NT + ct) * 3 + piece) * 64 + lane] = 8 bf16: W[mode * D + 32 kbi + 8 (lane >> 4) + i][16 ct + (lane & 15)],
 // i = 0..7, zero outside; g = mode * kbm + kbi (k-block kbi of the mode: 32 consecutive input columns).
@@ -698,15 +743,15 @@ constexpr size_t LDS_MAX = size_t(160) * 1024;
 unsigned long long *diag_buf3() {
   static unsigned long long *buf = nullptr;
   if (!buf) {
-    if (hipMalloc(&buf, 1024 * 16 * 4 * 8) != hipSuccess) buf = nullptr;
-    else (void)hipMemset(buf, 0, 1024 * 16 * 4 * 8);
+    if (hipMalloc(&buf, 1024 * 16 * 8 * 8) != hipSuccess) buf = nullptr;
+    else (void)hipMemset(buf, 0, 1024 * 16 * 8 * 8);
   }
   return buf;
 }
 #endif
 
-size_t lds_bytes3(const Shape3 &s, int nrt, int nimg, int nt, size_t rel_bytes) {
-  return size_t(nimg) * 3 * s.ncc * (nrt * 16) * 16 + 64 + size_t(2) * nt * 16 * 4 + rel_bytes;
+size_t lds_bytes3(const Shape3 &s, int nrt, int nimg, int nt, size_t rel_bytes) {   // one bf16 image, nimg f32 staging buffers
+  return size_t(3) * s.ncc * (nrt * 16) * 16 + size_t(nimg) * (nrt * 16) * s.ncc * 32 + 64 + size_t(2) * nt * 16 * 4 + rel_bytes;
 }
 
 template <int NT, int NRT, int NCH, bool RELLDS>
@@ -739,28 +784,29 @@ int launch3_nrt(const Args3 &p, int nrt, int grid, size_t lds, bool rel_lds, hip
 extern "C" int mgcn_diag_fused3(unsigned long long *host_out) {   // [1024][16][4] of the LAST gen-3 launch (diagnostics build)
   unsigned long long *b = diag_buf3();
   if (!b) return 1;
-  return hipMemcpy(host_out, b, 1024 * 16 * 4 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+  return hipMemcpy(host_out, b, 1024 * 16 * 8 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 #endif
 
 namespace mgcn {
 
 bool fused3_takes(int32_t dim_in, int32_t dim_out) {
-  return dim_in > 0 && dim_in % 4 == 0 && dim_in <= 1024 && dim_out > 0 && dim_out % 4 == 0 && dim_out <= 16 * NT3;
+  return dim_in > 0 && dim_in % 4 == 0 && dim_in <= 1024 && dim_out > 0 && dim_out % 4 == 0 && dim_out <= 512;
 }
 
-size_t fused3_packed_bytes(int32_t dim_in, int32_t) { return size_t(shape3(dim_in).G) * NT3 * 3 * 64 * 16; }
+size_t fused3_packed_bytes(int32_t dim_in, int32_t dim_out) { return size_t(shape3(dim_in).G) * pick_nt3(dim_out) * 3 * 64 * 16; }
 
 int fused3_pack(int32_t dim_in, int32_t dim_out, const float *w_dev, void *wp_dev, void *stream) {
   const Shape3 s = shape3(dim_in);
-  const int total = s.G * NT3 * 3 * 64;
+  const int nt = pick_nt3(dim_out);
+  const int total = s.G * nt * 3 * 64;
   hipLaunchKernelGGL(pack3_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w_dev,
-                     reinterpret_cast<u32x4 *>(wp_dev), dim_in, dim_out, s.kbm, NT3, total);
+                     reinterpret_cast<u32x4 *>(wp_dev), dim_in, dim_out, s.kbm, nt, total);
   MGCN_CHECK_LAUNCH("pack3_kernel");
   return MGCN_OK;
 }
 
-// tune: 0 = automatic; bits 0-3 row tiles per tile (3 / 4 / 5), bits 4-7 images (2 / 3), bits 8-9 relation table in LDS
+// tune: 0 = automatic; bits 0-3 row tiles per tile (3 / 4 / 5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS
 // (1 = never, 2 = whenever it fits): for A/B runs (tools/), never needed for correctness.
 int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
                   const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
@@ -792,31 +838,32 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   if (rpw < 16) rpw = 16;
   const int grid = int(nrows > 0 ? (nrows + rpw - 1) / rpw : 1);
   p.rows_per_wg = int32_t(rpw);
-  const int nt = NT3;
+  const int nt = pick_nt3(dim_out);
   const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;
-  // Geometry: the tallest tile (weight fragments feed 6 * NRT MFMAs) that leaves room for three images, else for two;
+  // Geometry: the tallest tile (weight fragments feed 6 * NRT MFMAs) that leaves room for three staging buffers, else two;
   // the relation table rides in LDS when it fits beside them (a third of the gather's row loads). Tiles taller than
   // the run are pointless.
   const int t_nrt = tune & 15, t_img = (tune >> 4) & 15, t_rel = (tune >> 8) & 3;
   int nrt = 0, nimg = 0;
   bool rel_lds = false;
-  const int nrt_cap = rpw >= 80 ? 5 : rpw >= 64 ? 4 : 3;
+  const int nrt_cap = nt == 32 ? 3 : rpw >= 80 ? 5 : rpw >= 64 ? 4 : 3;   // (32 column tiles: 48 accumulator registers at 3 row tiles)
   auto fits = [&](int a, int b, bool r) { return lds_bytes3(s, a, b, nt, r ? rel_bytes : 0) <= LDS_MAX; };
   const bool rel_wanted = rel_bytes > 0 && rel_bytes <= size_t(32) * 1024 && t_rel != 1;
   if (t_nrt || t_img) {
     nrt = t_nrt ? t_nrt : nrt_cap;
     nimg = t_img ? t_img : 2;
     rel_lds = rel_wanted && fits(nrt, nimg, true);
-    if (nrt < 3 || nrt > 5 || nimg < 2 || nimg > 4 || !fits(nrt, nimg, rel_lds))
+    if (nrt < 3 || nrt > nrt_cap || nimg < 1 || nimg > 4 || !fits(nrt, nimg, rel_lds))
       return mgcn::fail(MGCN_EINVAL, "layer_fwd_fused: tune %d does not fit the LDS", tune);
   } else {
     for (int want_rel = rel_wanted ? 1 : 0; want_rel >= 0 && !nrt; --want_rel) {
       for (int a = nrt_cap; a >= 3 && !nrt; --a) {
-        for (int b = 3; b >= 2 && !nrt; --b) {
+        for (int b = 3; b >= 2 && !nrt; --b) {   // (two staging buffers at least: the gather must be able to run ahead)
           if (fits(a, b, want_rel != 0)) { nrt = a; nimg = b; rel_lds = want_rel != 0; }
         }
       }
     }
+    if (!nrt && fits(3, 1, false)) { nrt = 3; nimg = 1; }   // 256-column passes (D > 248): one staging buffer
     if (!nrt) return mgcn::fail(MGCN_EUNSUPPORTED, "layer_fwd_fused: no tile geometry fits the LDS (D=%d O=%d)", dim_in, dim_out);
   }
   p.nimg = nimg;
@@ -825,8 +872,12 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
 #endif
   const size_t lds = lds_bytes3(s, nrt, nimg, nt, rel_lds ? rel_bytes : 0);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (s.nch == 1) return launch3_nrt<NT3, 1>(p, nrt, grid, lds, rel_lds, st);
-  return launch3_nrt<NT3, 2>(p, nrt, grid, lds, rel_lds, st);
+  if (nt == 32) {
+    if (s.nch == 1) return launch3_rel<32, 3, 1>(p, grid, lds, rel_lds, st);
+    return launch3_rel<32, 3, 2>(p, grid, lds, rel_lds, st);
+  }
+  if (s.nch == 1) return launch3_nrt<13, 1>(p, nrt, grid, lds, rel_lds, st);
+  return launch3_nrt<13, 2>(p, nrt, grid, lds, rel_lds, st);
 }
 
 }  // namespace mgcn

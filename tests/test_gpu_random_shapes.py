@@ -32,6 +32,15 @@ def test_fused_layer_random_shapes(seed):
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize('seed', [13, 14])
+def test_fused_layer_wide_shapes(seed):
+    """input widths beyond one 256-column pass (D in 200..1024: one, two, four passes) and outputs beyond
+    13 column tiles (O up to 512: the 32-column-tile instance), same checks as above."""
+    ok, worst = _tool('stress_fused').run(seed=seed, trials=10, keep_going=False, wide=True)
+    assert ok, 'fused layer (wide shapes) differs from the two-launch path / the oracle (see the trial printed last)'
+    assert worst < 1e-4
+
+
 def test_score_and_rank_random_shapes():
     assert _tool('stress_rank').run(seed=21, trials=16)
 

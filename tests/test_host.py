@@ -481,16 +481,16 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         ('mgcn_label_rows', (4, N, 0, N, N, N, 0, 8, 1.0, 0.0, N, 4, N), 'leading|sizes|null'),
         ('mgcn_score_bce_fwd', (4, 8, 4, N, 4, N, 4, N, N, 1, 1.0, 0.0, 0.1, N, 4, N, N), 'null pointer'),
         ('mgcn_matmul_f32', (4, 4, 4, N, 4, N, 4, N, 4, N), 'null pointer'),
-        ('mgcn_pack_weights', (4, 4, N, N, 0, 0, N), 'bad arguments'),
+        ('mgcn_pack_weights', (4, 4, N, N, 0, N), 'bad arguments'),
     ]
     for name, args, pattern in cases:
         rc = getattr(lib, name)(*args)
         msg = lib.mgcn_last_error().decode()
         assert rc == 1, (name, rc, msg)
         assert re.search(pattern, msg), (name, msg)
-    # second-generation fused layer: 3 modes x 4 k-blocks of 32 (100 -> 128 columns) x 13 column tiles x 3 bf16 pieces x 1 KiB
-    assert lib.mgcn_packed_weights_bytes(100, 200, 0) == 3 * 4 * 13 * 3 * 64 * 16
-    assert lib.mgcn_packed_weights_bytes(200, 200, 0) == 3 * 7 * 13 * 3 * 64 * 16   # ceil(200 / 32) = 7 k-blocks per mode
+    # fused layer: 3 modes x 4 k-blocks of 32 (100 -> 128 columns) x 13 column tiles x 3 bf16 pieces x 1 KiB
+    assert lib.mgcn_packed_weights_bytes(100, 200) == 3 * 4 * 13 * 3 * 64 * 16
+    assert lib.mgcn_packed_weights_bytes(200, 200) == 3 * 7 * 13 * 3 * 64 * 16   # ceil(200 / 32) = 7 k-blocks per mode
     assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
     assert lib.mgcn_score_bce_partials(128, 40943) == 1280
 

@@ -96,21 +96,15 @@ def main():
                 if hasattr(nat.lib(), 'mgcn_diag_fused3') and (tune >> 10) & 3 == 3:   # diagnostics build: who waits for whom
                     import ctypes
                     import numpy as np
-                    buf = np.zeros((1024, 16, 4), dtype=np.uint64)
+                    buf = np.zeros((1024, 16, 8), dtype=np.uint64)
                     if nat.lib().mgcn_diag_fused3(ctypes.c_void_p(buf.ctypes.data)) == 0:
                         used = buf[:, 0, 0] > 0
-                        d = buf[used].astype(np.float64)
-                        t0 = d[:, :8, 3].min()
-                        r['diag'] = {
-                            'wgs': int(used.sum()),
-                            'multiply_kcycles': [round(float(d[:, :8, 0].mean()) / 1e3, 1), round(float(d[:, :8, 0].max()) / 1e3, 1)],
-                            'multiply_wait_kcycles': round(float(d[:, :8, 1].mean()) / 1e3, 1),
-                            'gather_kcycles': [round(float(d[:, 8:, 0].mean()) / 1e3, 1), round(float(d[:, 8:, 0].max()) / 1e3, 1)],
-                            'gather_wait_kcycles': round(float(d[:, 8:, 1].mean()) / 1e3, 1),
-                            'gather_load_wait_kcycles': round(float(d[:, 8:, 2].mean()) / 1e3, 1),
-                            'gather_batches': round(float(d[:, 8:, 3].mean()), 1),
-                            'start_skew_kcycles': round(float((d[:, 0, 3] - t0).max()) / 1e3, 1),
-                            'end_kcycles': round(float((d[:, :8, 3] + d[:, :8, 0]).max() - t0) / 1e3, 1)}
+                        d = buf[used].astype(np.float64) / 1e3
+                        names = ['total', 'ring_wait', 'load_wait', 'batches', 'a', 'b', 'd', 'o']
+                        r['diag'] = {'wgs': int(used.sum()),
+                                     'multiply(total,ring+phase waits,-,-,convert,conv_wait,mfma,other)': [round(float(d[:, :8, i].mean()), 1) for i in range(8)],
+                                     'gather(total,ring_wait,load_wait,kbatches,issue,prefetch_next,consume,other)': [round(float(d[:, 8:, i].mean()), 1) for i in range(8)],
+                                     'gather_total_max': round(float(d[:, 8:, 0].max()), 1), 'multiply_total_max': round(float(d[:, :8, 0].max()), 1)}
                 entry['tunes'][hex(tune)] = r
         res['layers'].append(entry)
         x, rel = ref, rel_ref

@@ -10,14 +10,20 @@ from oracle import mgcn_oracle as oracle
 dev = torch.device('cuda:0')
 
 
-def run(seed=0, trials=60, keep_going=False):
+DIMS_IN = [4, 8, 36, 64, 100, 128, 200, 256]
+DIMS_OUT = [4, 16, 32, 60, 64, 128, 200, 208]
+WIDE_IN = [200, 256, 260, 384, 512, 1024]      # 256-column passes: one, two, four of them
+WIDE_OUT = [200, 208, 212, 256, 320, 512]      # 13 and 32 column tiles
+
+
+def run(seed=0, trials=60, keep_going=False, wide=False):
     """-> (all trials ok, worst deviation); tests/test_gpu_random_shapes.py runs a short instance of it."""
     rng = np.random.default_rng(seed)
     worst = 0.0
     bad = False
     for trial in range(trials):
         N = int(rng.integers(1, 700)); R = int(rng.integers(1, 9)); E = int(rng.integers(0, 4000))
-        D = int(rng.choice([4, 8, 36, 64, 100, 128, 200, 256])); O = int(rng.choice([4, 16, 32, 60, 64, 128, 200, 208]))
+        D = int(rng.choice(WIDE_IN if wide else DIMS_IN)); O = int(rng.choice(WIDE_OUT if wide else DIMS_OUT))
         zipf = float(rng.choice([0.0, 1.2]))
         s = rng.integers(0, N, E)
         if zipf > 0 and N > 1:
@@ -79,5 +85,5 @@ def run(seed=0, trials=60, keep_going=False):
 
 if __name__ == '__main__':
     ok, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 60,
-                bool(os.environ.get('STRESS_KEEP_GOING')))
+                bool(os.environ.get('STRESS_KEEP_GOING')), wide=bool(os.environ.get('STRESS_WIDE')))
     sys.exit(0 if ok else 1)
