@@ -73,17 +73,21 @@ __device__ __forceinline__ float tanh3_(float v) {   // exp2 + rcp, 7 VALU per v
   return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
 }
 
-// Exact three-way split of an f32 into bf16 pieces by truncation (hi + mid + lo == v bit for bit for finite v; a
-// non-finite v gives NaN pieces, i.e. a NaN output row where the exact-f32 path may give +-1: documented in DESIGN.md).
-__device__ __forceinline__ void split3(float v, uint32_t &h, uint32_t &m, uint32_t &l) {
-  h = __float_as_uint(v) & 0xffff0000u;
-  const float r1 = v - __uint_as_float(h);
-  m = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(m);
-  l = __float_as_uint(r2);
-}
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t even, uint32_t odd) {   // {even >> 16, odd >> 16}
-  return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+// Exact three-way split of two f32 values into bf16 pieces, packed {even, odd}: hi = bf16(v) (round to nearest even),
+// mid = bf16(v - hi), lo = v - hi - mid. Each difference is exact (v - hi has at most 16 significant bits, the next
+// one at most 8), so hi + mid + lo == v bit for bit for finite v. Rounding (not truncating) keeps every residual at
+// most HALF an ulp of the piece above it, with either sign: the cross terms the multiply drops (mid x lo, lo x mid, lo x
+// lo) are below 2^-26 |a| |w| and unbiased, where a truncating split leaves 2^-24 with the sign of the product
+// (tests/test_gpu_round3.py feeds rows with 2^40 of dynamic range). A non-finite v gives NaN pieces: the output row is
+// NaN where the exact-f32 path may give +-1 (documented in DESIGN.md).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3p(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{v0, v1}, bf16x2));            // v_cvt_pk_bf16_f32
+  const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
 }
 __device__ __forceinline__ float4 f4mul3(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4axpy(float4 s, float4 m, float w) {
@@ -614,15 +618,13 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
         const int coff = cc * BM * 16 + (ql & 1) * 8;
         const int crot = (cc >> 1) & 7;
         auto convert_row = [&](int row, const float4 &v) __attribute__((always_inline)) {
-          uint32_t h[4], m[4], l[4];
-          split3(v.x, h[0], m[0], l[0]);
-          split3(v.y, h[1], m[1], l[1]);
-          split3(v.z, h[2], m[2], l[2]);
-          split3(v.w, h[3], m[3], l[3]);
+          uint32_t h[2], m[2], l[2];
+          split3p(v.x, v.y, h[0], m[0], l[0]);
+          split3p(v.z, v.w, h[1], m[1], l[1]);
           unsigned char *dst = lds3 + coff + ((row & ~15) + (((row & 15) + crot) & 15)) * 16;
-          *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-          *reinterpret_cast<uint2 *>(dst + piece) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-          *reinterpret_cast<uint2 *>(dst + 2 * piece) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+          *reinterpret_cast<uint2 *>(dst) = make_uint2(h[0], h[1]);
+          *reinterpret_cast<uint2 *>(dst + piece) = make_uint2(m[0], m[1]);
+          *reinterpret_cast<uint2 *>(dst + 2 * piece) = make_uint2(l[0], l[1]);
         };
         if (qok) {
           const unsigned char *src = stg + ql * 16;
@@ -702,29 +704,28 @@ __global__ __launch_bounds__(256) void pack3_kernel(const float *__restrict__ w,
   const int lane = idx & 63, piece = (idx >> 6) % 3, ct = ((idx >> 6) / 3) % nt, g = (idx >> 6) / (3 * nt);
   const int mode = g / kbm, kbi = g - mode * kbm;
   const int col = ct * 16 + (lane & 15), k0 = 32 * kbi + 8 * (lane >> 4);
-  uint32_t bits[8];
+  uint32_t bits[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = k0 + i;
-    const float v = (k < d && col < o) ? w[(int64_t(mode) * d + k) * o + col] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + 2 * i + j;
+      v[j] = (k < d && col < o) ? w[(int64_t(mode) * d + k) * o + col] : 0.f;
+    }
     uint32_t h, m, l;
-    split3(v, h, m, l);
+    split3p(v[0], v[1], h, m, l);
     bits[i] = piece == 0 ? h : piece == 1 ? m : l;
   }
-  u32x4 r;
-  r.x = pack_hi16(bits[0], bits[1]);
-  r.y = pack_hi16(bits[2], bits[3]);
-  r.z = pack_hi16(bits[4], bits[5]);
-  r.w = pack_hi16(bits[6], bits[7]);
-  wp[idx] = r;
+  wp[idx] = u32x4{bits[0], bits[1], bits[2], bits[3]};
 }
 
 struct Shape3 {
   int nch, npass, nkb_last, kbp, kbm, G, ncc;
 };
-Shape3 shape3(int d) {
+Shape3 shape3(int d, int nch = 0) {   // nch: float4 per lane and slot walk (0 = by width)
   Shape3 s;
-  s.nch = d > 128 ? 2 : 1;
+  s.nch = nch ? nch : ((d > 128 && d <= 256) ? 2 : 1);   // wider inputs: 128-column passes leave room for 80-row tiles
   const int wpass = 128 * s.nch;
   s.npass = (d + wpass - 1) / wpass;
   const int wlast = d - wpass * (s.npass - 1);
@@ -807,7 +808,8 @@ int fused3_pack(int32_t dim_in, int32_t dim_out, const float *w_dev, void *wp_de
 }
 
 // tune: 0 = automatic; bits 0-3 row tiles per tile (3 / 4 / 5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS
-// (1 = never, 2 = whenever it fits): for A/B runs (tools/), never needed for correctness.
+// (1 = never, 2 = whenever it fits), bits 12-13 columns per slot walk (1 = 128, 2 = 256): for A/B runs (tools/), never
+// needed for correctness (the packed weights do not depend on it).
 int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
                   const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
                   const float *loop_rel_dev, const float *ee_dev, const float *loop_edge_dev, const void *wp_dev,
@@ -815,7 +817,9 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
                   const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
                   int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
                   const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream) {
-  const Shape3 s = shape3(dim_in);
+  const int t_nch = (tune >> 12) & 3;
+  if (t_nch > 2) return mgcn::fail(MGCN_EINVAL, "layer_fwd_fused: bad tune %d", tune);
+  const Shape3 s = shape3(dim_in, t_nch);
   Args3 p = {};
   p.rowptr = rowptr_dev; p.rec = reinterpret_cast<const int4 *>(rec_dev);
   p.x = x_dev; p.rel = rel_dev; p.loop_rel = loop_rel_dev; p.ee = ee_dev; p.loop_edge = loop_edge_dev;
@@ -849,7 +853,7 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   const int nrt_cap = nt == 32 ? 3 : rpw >= 80 ? 5 : rpw >= 64 ? 4 : 3;   // (32 column tiles: 48 accumulator registers at 3 row tiles)
   auto fits = [&](int a, int b, bool r) { return lds_bytes3(s, a, b, nt, r ? rel_bytes : 0) <= LDS_MAX; };
   const bool rel_wanted = rel_bytes > 0 && rel_bytes <= size_t(32) * 1024 && t_rel != 1;
-  if (t_nrt || t_img) {
+  if (t_nrt || t_img || t_nch) {
     nrt = t_nrt ? t_nrt : nrt_cap;
     nimg = t_img ? t_img : 2;
     rel_lds = rel_wanted && fits(nrt, nimg, true);

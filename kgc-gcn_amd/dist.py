@@ -48,10 +48,20 @@ class FilterIndex(object):
         return sub.to(torch.int64) * self.num_rel_ids + rel.to(torch.int64)
 
 
+def _gather_into(out, t, group):
+    """out [world * n, ...] <- every rank's t [n, ...], in rank order: ONE collective writing straight into `out`
+    (all_gather_into_tensor; the list form costs a staging copy per rank on RCCL — 20.5 GB per layer at BASELINE
+    configs[4]). Backends without it (old gloo builds) take the list form over views of `out`."""
+    t = t.contiguous()
+    try:
+        dist.all_gather_into_tensor(out, t, group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather(list(out.chunk(out.size(0) // max(t.size(0), 1), dim=0)) if t.size(0) else [], t, group=group)
+    return out
+
+
 def _gather(t, group, world):
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t.contiguous(), group=group)
-    return torch.cat(out, dim=0)
+    return _gather_into(t.new_empty((world * t.size(0),) + tuple(t.shape[1:])), t, group)
 
 
 def sharded_rank_counts(x, qkey, obj, ent_shard, bias_shard, row0, filt, group=None, kernels=_native):
@@ -123,11 +133,15 @@ def encode_layer_rows(layer, csr, x, rel, table_shard, n0, n1, ee_sub, out=None)
         out = torch.empty((n1 - n0, O), dtype=torch.float32, device=x.device)
     wcat, wpack = layer.derived_weights()
     x, rel = x.contiguous(), rel.contiguous()
-    if wpack is not None:
-        _native.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table_shard, True, layer.loop_edge.reshape(-1),
-                                wpack, O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
-                                node_range=(n0, n1), ee_sub=ee_sub)
-    elif n1 > n0:
+    fused = wpack is not None
+    if fused:
+        try:
+            _native.layer_fwd_fused(csr, x, rel, layer.loop_rel.reshape(-1), table_shard, True, layer.loop_edge.reshape(-1),
+                                    wpack, O, layer.bias, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out,
+                                    node_range=(n0, n1), ee_sub=ee_sub)
+        except _native.FusedUnsupported:      # e.g. a misaligned operand: the two launches on the range, as MGCNConv.forward
+            fused = False
+    if not fused and n1 > n0:
         # the aggregate of the range only ([n1 - n0, 3D]); the kernel writes rows by global node id, hence the offset view
         agg = torch.empty((n1 - n0, 3 * layer.in_channels), dtype=torch.float32, device=x.device)
         _native.aggregate_fwd(csr, x, rel, table_shard, True, layer.loop_edge.reshape(-1), agg, loop_rel=layer.loop_rel.reshape(-1),
@@ -156,6 +170,11 @@ def encode_sharded(model, graph, group=None):
     b = csr.balanced_bounds(world)          # equal work (slots + nodes) per rank, not equal node counts (degree skew)
     n0, n1, chunk = b[rank], b[rank + 1], max(b[r + 1] - b[r] for r in range(world))
     if model._edge_shard is not None:
+        ent_identity, edge_identity = model._graph_facts(graph)
+        if not (ent_identity and edge_identity):
+            # shard_model_tables filled the shard by csr.perm = edge-list POSITIONS: only right when edge k has id k
+            raise _native.NativeError('encode_sharded: a model that holds a table shard needs a graph whose entity and edge ids '
+                                      'are the identity (data_loader.py:113,147-149 builds them so)')
         if model._edge_shard[0] is not csr or model._edge_shard[1:] != (n0, n1):
             raise _native.NativeError('encode_sharded: the model holds the table shard of destinations %s, this rank owns (%d, %d)'
                                       % (model._edge_shard[1:], n0, n1))
@@ -181,7 +200,7 @@ def encode_sharded(model, graph, group=None):
         encode_layer_rows(layer, csr, x, rel, shard, n0, n1, ee_sub, out=local[:n1 - n0])
         if world > 1:
             full = torch.empty((world * chunk, layer.out_channels), dtype=torch.float32, device=x.device)
-            dist.all_gather(list(full.chunk(world, dim=0)), local, group=group)   # equal (padded) chunks, gathered in place
+            _gather_into(full, local, group)                                    # equal (padded) chunks, gathered in place
             if all(b[r + 1] - b[r] == chunk for r in range(world - 1)):
                 x = full[:N]
             else:                                                              # drop each rank's padding rows

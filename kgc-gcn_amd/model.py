@@ -446,7 +446,9 @@ class MGCN(nn.Module):
             n, e2 = self.entity_embedding.size(0), self.edge_embeddings.size(0)
             ent_id = data.entity.numel() == n and bool((data.entity == torch.arange(n, device=data.entity.device)).all())
             ids = data.edge_attr[1]
-            edge_id = ids.numel() == e2 and bool((ids == torch.arange(e2, device=ids.device)).all())
+            # (a model that holds a table shard has fewer rows than the graph has edges: only the ids themselves count)
+            edge_id = (self._edge_shard is not None or ids.numel() == e2) and \
+                bool((ids == torch.arange(ids.numel(), device=ids.device)).all())
             facts = (key, ent_id, edge_id)
             data._mgcn_facts = facts
         return facts[1], facts[2]
