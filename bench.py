@@ -41,7 +41,8 @@ SHAPES = {  # public dataset shapes
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA: what the algorithmic flops of the dense step cost in f32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA: what the kernel's six split products are issued on
-KERNEL_SOURCES = ('layer_fused2.hip', 'layer_fused.hip', 'aggregate.hip')
+KERNEL_SOURCES = ('layer_fused2.hip', 'layer_fused3.hip', 'layer_fused.hip', 'aggregate.hip')
+TRAFFIC_FILE = 'r03_traffic.json'
 
 
 def synth_graph(shape, seed=0, zipf=0.0):
@@ -74,15 +75,18 @@ def agg_kernel_bytes(N, E2, R2, D):
 
 
 def split_mfma_flops(N, D, O):
-    """MFMA flops the fused kernel actually issues per layer: six bf16 products over K padded to 32-wide k-blocks per
-    128-column chunk and O padded to 16-wide column tiles, 80-row tiles."""
-    kblocks, left = 0, D
-    while left > 0:
-        w = min(left, 128)
-        kblocks += (w + 31) // 32
-        left -= w
-    rows = (N + 79) // 80 * 80
-    return 6 * 2.0 * rows * (3 * kblocks * 32) * ((O + 15) // 16 * 16)
+    """MFMA flops the fused kernel actually issues per layer: six bf16 products over K padded to 32-wide k-blocks, the
+    output padded to 13 (O <= 208) or 32 column tiles of 16, rows to 16-row tiles."""
+    if D <= 256 and O <= 208:     # layer_fused2.hip: 128-column chunks, 80-row tiles, column tiles by O
+        kblocks, left = 0, D
+        while left > 0:
+            w = min(left, 128)
+            kblocks += (w + 31) // 32
+            left -= w
+        return 6 * 2.0 * ((N + 79) // 80 * 80) * (3 * kblocks * 32) * ((O + 15) // 16 * 16)
+    kblocks = (D + 31) // 32        # layer_fused3.hip
+    rows = (N + 15) // 16 * 16
+    return 6 * 2.0 * rows * (3 * kblocks * 32) * (208 if O <= 208 else 512)
 
 
 def spawn_ranks(args):
@@ -151,6 +155,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
     ap.add_argument('--no-fb', action='store_true', help='skip the FB15k-237-shape sub-objects (configs[2], configs[3])')
+    ap.add_argument('--no-scale', action='store_true', help='skip the "scale" object (partitioned encoder, configs[4] slice)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -218,6 +223,12 @@ def main():
         ev = eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank)
         if rank == 0:
             result['eval'] = ev
+    scale = {}
+    if not args.no_scale:                                   # every rank takes part
+        if rank != 0 and args.no_eval:                      # (the partitioned encoder needs ONE graph on all ranks: rank 0's)
+            del model, graph
+            model, graph, params, edge_index, edge_attr = make_model(pkg, shape, dev, args.layers, 0, args.zipf)
+        scale[args.shape] = guarded(lambda: encode_sharded_timing(pkg, model, graph, shape, dev, world, rank, dist, O))
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         result['cpu_baseline'] = cpu_baseline(model, edge_index, edge_attr, args.shape, args.layers, N, R, E, D, O, 20.0)
         result['config']['gpu_over_cpu'] = value / result['cpu_baseline']['value']
@@ -234,6 +245,18 @@ def main():
             result['fb15k237'] = fb['step']
             if 'eval' in fb:
                 result.setdefault('eval', {})['fb15k237'] = fb['eval']
+        if 'scale' in fb:
+            scale['fb15k237'] = fb['scale']
+    if not args.no_scale:
+        torch.cuda.empty_cache()
+        scale['config5_slice'] = guarded(lambda: config5_slice(pkg, dev, world, rank, dist))
+        if rank == 0:
+            scale['note'] = ('SURVEY 8(e) measured: "encode_sharded_s" = the destination-partitioned 2-layer encoder (each rank its '
+                             'work-balanced destination range and table shard, all-gather of every layer output included), same '
+                             'graph on all ranks: strong scaling against "one_rank_s" (rank 0 alone, same process, no '
+                             'collective); "config5_slice" = one rank\'s 1/8 of a 2M-entity / 20M-triple / dim-512 layer '
+                             '(BASELINE configs[4] scaled to what one box builds in seconds), every rank its own slice')
+            result['scale'] = scale
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -267,6 +290,117 @@ def real_dataset_sections(pkg, args, dev, D, O):
     return out
 
 
+def guarded(fn):
+    """Optional sections must not take the headline down with them: an exception becomes {'error': ...} (all ranks run
+    the same code, so a failure is the same on every rank and no collective is left half-entered)."""
+    try:
+        return fn()
+    except Exception as err:                                # noqa: BLE001 (reported in the JSON line)
+        print('bench.py: optional section failed: %r' % (err,), file=sys.stderr)
+        return {'error': repr(err)[:300]}
+
+
+def encode_sharded_timing(pkg, model, graph, shape, dev, world, rank, dist, O):
+    """SURVEY 8(e) on the wire: dist.encode_sharded — every rank computes the rows of its work-balanced destination range
+    for both layers from its shard of the slot-ordered per-edge tables, and every layer output is all-gathered (RCCL) —
+    timed on the SAME graph on all ranks (strong scaling), best of 5, max over ranks; rank 0 alone (a one-rank group, no
+    collective) right after, in the same process."""
+    N, R, E = shape['N'], shape['R'], shape['E']
+    csr = graph.csr(2 * R + 1)
+    b = csr.balanced_bounds(world)
+    rp = csr.rowptr.cpu()
+    work = [int((rp[0, b[r + 1]] - rp[0, b[r]]) + (rp[1, b[r + 1]] - rp[1, b[r]])) + (b[r + 1] - b[r]) for r in range(world)]
+    out = {'world': world, 'layers': 1 + len(model.conv1_extra), 'rows_per_rank': [b[r + 1] - b[r] for r in range(world)],
+           'edges_per_rank_excluding_hub_slots': work, 'allgather_bytes_per_layer': N * O * 4}
+
+    def run(group):
+        best = None
+        for _ in range(5):
+            model._enc_cache = None
+            if dist is not None and group is None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pkg.dist.encode_sharded(model, graph, group=group)
+            torch.cuda.synchronize()
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        return best
+
+    t = run(None)
+    if dist is not None:
+        tt = torch.tensor([t], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    out['encode_sharded_s'] = t
+    out['edges_per_s'] = out['layers'] * (2 * E + N) / t
+    if world > 1:
+        solo = dist.new_group([0])                          # (every rank takes part in creating it)
+        if rank == 0:
+            out['one_rank_s'] = run(solo)
+            out['speedup_vs_one_rank'] = out['one_rank_s'] / t
+        dist.barrier()
+    else:
+        out['one_rank_s'] = t
+    return out
+
+
+def config5_slice(pkg, dev, world, rank, dist, N=2000000, E=20000000, R=1000, D=512, O=512, parts=8):
+    """One rank's 1/8 of BASELINE configs[4]'s layer through the PRODUCT path of a destination-partitioned rank (the rank's
+    model holds ONLY its shard of the per-edge table: params.edge_table_rows + dist.shard_model_tables, rows from the
+    chunk-wise xavier table), scaled to a graph one box builds in seconds: 2M entities, 20M triples, 1k relations,
+    dim 512 -> 512. Rank r takes slice r % 8; nothing is cache-resident (10 GB of table rows per rank)."""
+    part = rank % parts
+    rng = np.random.default_rng(0)
+    s, r, o = rng.integers(0, N, E), rng.integers(0, R, E), rng.integers(0, N, E)
+    ei = torch.from_numpy(np.stack((np.concatenate((s, o)), np.concatenate((o, s)))))
+    et = torch.from_numpy(np.concatenate((r, r + R)))
+    del s, r, o
+    csr = pkg.GraphCSR(N, 2 * R + 1, ei, et, dev, with_backward=False)
+    del ei, et
+    b = csr.balanced_bounds(parts)
+    n0, n1 = b[part], b[part + 1]
+    rows = sum(csr.shard_slot_counts(n0, n1))
+    params = types.SimpleNamespace(gcn_in_dim=D, gcn_out_dim=O, gcn_drop=0.3, hidden_drop=0.3, feat_drop=0.3, k_w=8, k_h=O // 8,
+                                   num_filter=4, kernel_size=3, bias=False, lbl_smooth=0.1, gcn_layers=1, edge_table_rows=rows)
+    torch.manual_seed(0)
+    model = pkg.MGCN(N, R, E, params).to(dev).eval()
+    pkg.dist.shard_model_tables(model, csr, n0, n1, lambda li, ids: pkg.dist.xavier_rows(ids, 2 * E, D, 11 + li, dev))
+    layer, table = model.conv1, model.edge_embeddings.detach()
+    x, rel = model.entity_embedding.detach(), model.relation_embedding.detach()
+    out_rows = torch.empty((n1 - n0, O), device=dev)
+    ee_sub = csr.shard_ee_sub(n0, n1)
+
+    def run():
+        with torch.no_grad():
+            pkg.dist.encode_layer_rows(layer, csr, x, rel, table, n0, n1, ee_sub, out=out_rows)
+
+    run()
+    torch.cuda.synchronize()
+    a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        run()
+    c.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(c) / 5
+    if dist is not None:
+        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+    # compulsory bytes of the rank's share: its per-edge rows + records, the x rows its slots gather (the 4 GB table is far
+    # past every cache, so a gathered row is a DRAM access), its own x rows, its output rows
+    gathered = rows * (4 * D + 4 * D + 16) + (n1 - n0) * (4 * D + 4 * O)
+    res = {'graph': 'N=%d E=%d R=%d dim %d->%d, slice %d of %d' % (N, E, R, D, O, part, parts), 'slots_this_rank': rows,
+           'table_shard_GB': table.numel() * 4 / 1e9, 'whole_table_GB': 2 * E * D * 4 / 1e9, 'layer_ms_max_over_ranks': ms,
+           'edges_per_s_per_rank': (rows + (n1 - n0)) / ms * 1e3, 'gathered_GBps': gathered / ms / 1e6,
+           'frac_of_8TBps': gathered / ms / 1e6 / HBM_PEAK_GBS,
+           'path': 'fused' if pkg._native.fused_supported(D, O) else 'aggregate + dense'}
+    del model, table, csr, out_rows
+    torch.cuda.empty_cache()
+    return res
+
+
 def fb_sections(pkg, args, dev, world, rank, dist, barrier, D, O):
     """BASELINE configs[2] (the encoder step on the FB15k-237 shape, hub-heavy Zipf(1.1) tails: "denser graph,
     HBM-bound gather") and configs[3] (its full evaluation with the entity table sharded over the ranks)."""
@@ -290,6 +424,8 @@ def fb_sections(pkg, args, dev, world, rank, dist, barrier, D, O):
         out['step'] = step
     else:
         out['step'] = None
+    if not args.no_scale:
+        out['scale'] = guarded(lambda: encode_sharded_timing(pkg, model, graph, shape, dev, world, rank, dist, O))
     if not args.no_eval:
         out['eval'] = fb_eval(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank, dist)
     return out
@@ -312,6 +448,7 @@ def fb_eval(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world,
                           np.stack((np.where(fwd, s, o), np.where(fwd, r, r - R), np.where(fwd, o, s)), axis=1)]).astype(np.int64)
     keys, ptr, tails = pkg._native.filter_index_build(torch.from_numpy(tri), R)   # both directions of every known triple
     filt = pkg.dist.FilterIndex(keys, ptr, tails, 2 * R).to(dev)
+    scale_tables(model)
     params.cache_encoder = True
     out = {'queries': 2 * n_eval, 'batch': 128, 'world': world}
     solo = None
@@ -493,12 +630,12 @@ def kernel_breakdown(pkg, model, graph, K, shape, shape_name, n_layers, D, O):
     # in separate passes, corrected as MI355X_MICROARCH.md prescribes), committed under profiles/. The file carries the
     # fingerprint of the kernel sources it was measured on: a stale file is NOT quoted.
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', TRAFFIC_FILE)) as f:
             tj = json.load(f)
         traffic = tj.get(shape_name, {})
         if tj.get('source_fingerprint') != source_fingerprint():
-            roof['traffic_note'] = 'profiles/r02_traffic.json was measured on other kernel sources (%s != %s): not quoted' % (
-                tj.get('source_fingerprint'), source_fingerprint())
+            roof['traffic_note'] = 'profiles/%s was measured on other kernel sources (%s != %s): not quoted' % (
+                TRAFFIC_FILE, tj.get('source_fingerprint'), source_fingerprint())
             print('bench.py: ' + roof['traffic_note'], file=sys.stderr)
         elif dom in traffic:
             roof['traffic'] = traffic[dom]['traffic_bytes']
@@ -508,6 +645,22 @@ def kernel_breakdown(pkg, model, graph, K, shape, shape_name, n_layers, D, O):
     except (OSError, KeyError, ValueError) as err:
         roof['traffic_note'] = 'no PMC traffic file: %s' % err
     return {'roofline': roof, 'kernels': kern}
+
+
+def scale_tables(model):
+    """xavier tables of these sizes are tiny (|x| ~ 1e-2): an untrained model then scores every entity 0.5 +- 1e-6 and a rank
+    check decides nothing. Scaled as tests/test_gpu_bench_shapes.py scales them, layer outputs are O(0.1 - 1) and the
+    scores of one query spread over (0.05, 0.95): ranks have margins, so "same ranks as the reference order" has teeth.
+    (In place, once, after the timed encoder step: kernel times do not depend on the values.)"""
+    if getattr(model, '_bench_scaled', False):
+        return
+    with torch.no_grad():
+        model.entity_embedding.mul_(30.0)
+        model.relation_embedding.mul_(3.0)
+        for t in [model.edge_embeddings] + list(model.edge_embeddings_extra):
+            t.mul_(100.0)
+    model._bench_scaled = True
+    model._enc_cache = None
 
 
 def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr, world, rank):
@@ -537,6 +690,7 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
         known.setdefault((int(a), int(t)), set()).add(int(bb))
     filt = pkg.dist.FilterIndex.from_known(known, 2 * R).to(dev)
     out = {'queries': 2 * n_eval, 'batch': B, 'world': world}
+    scale_tables(model)
     params.cache_encoder = True
     for name, bs in (('sharded_bits_s', B), ('sharded_bits_oneshot_s', None)):
         for _ in range(2):
@@ -564,6 +718,7 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
                 t0 = time.perf_counter()
                 with torch.no_grad():
                     acc = torch.zeros((), dtype=torch.float64, device=dev)
+                    all_ranks = []
                     for q, lab in batches:
                         if fused:
                             counts, _ = model.rank_counts(q[:, 0], q[:, 1], q[:, 2].contiguous(), lab, graph)
@@ -571,10 +726,19 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
                         else:
                             ranks = pkg.harness.ranks_from_scores(model(q[:, 0], q[:, 1], graph), lab, q[:, 2])
                         acc += (1.0 / ranks.double()).sum()
+                        all_ranks.append(ranks.to(torch.int64))
                     mrr = float(acc.item()) / (2 * n_eval)
                 torch.cuda.synchronize()
                 out[name] = time.perf_counter() - t0
             out[name.replace('_s', '_mrr')] = mrr
+            out[name.replace('_s', '_ranks')] = torch.cat(all_ranks)
+        # parity with teeth: per-query ranks of the HIP count path against the reference's own order of operations
+        # (main.py:117-126: scores, mask, double argsort) on a model whose scores have margins (scale_tables)
+        ours, ref = out.pop('fused_dense_ranks'), out.pop('reference_order_ranks')
+        out['rank_rows'] = int(ours.numel())
+        out['rank_rows_equal_reference_order'] = int((ours == ref).sum())
+        out['mean_rank_reference_order'] = float(ref.double().mean())
+        assert out['rank_rows_equal_reference_order'] >= 0.995 * out['rank_rows'], out
         assert abs(out['sharded_bits_mrr'] - out['reference_order_mrr']) <= 1e-4, out
         assert abs(out['fused_dense_mrr'] - out['reference_order_mrr']) <= 1e-4, out
     params.cache_encoder = False

@@ -1,6 +1,6 @@
 // Fused layer forward (eval) — C-ABI entry points: mgcn_pack_weights / mgcn_packed_weights_bytes /
 // mgcn_layer_fwd_fused (include/mgcn_hip.h (2)+(4)); replaces model.py:29-30, 99-107, 111-118 in one launch.
-// The kernel is layer_fused3.hip.
+// The kernels are layer_fused2.hip (D <= 256, O <= 208) and layer_fused3.hip (the rest).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -8,8 +8,15 @@
 #include "mgcn_common.h"
 
 
+namespace {
+// Two kernels behind one entry point. layer_fused2.hip (one workgroup barrier per stage: every workgroup walks the packed
+// weights in step, which keeps them L2-resident while the step's alternating layers stream 330 MB through the caches)
+// takes D <= 256, O <= 208; layer_fused3.hip (ring of staging buffers, O up to 512, 256-column passes) takes the rest.
+bool lockstep_shape(int32_t dim_in, int32_t dim_out) { return dim_in <= 256 && mgcn::fused2_takes(dim_in, dim_out); }
+}  // namespace
+
 extern "C" size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out) {
-  return mgcn::fused3_packed_bytes(dim_in, dim_out);
+  return lockstep_shape(dim_in, dim_out) ? mgcn::fused2_packed_bytes(dim_in, dim_out) : mgcn::fused3_packed_bytes(dim_in, dim_out);
 }
 
 extern "C" int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes,
@@ -17,6 +24,7 @@ extern "C" int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w
   MGCN_REQUIRE(dim_in > 0 && dim_out > 0 && w_dev && wp_dev, "pack_weights: bad arguments");
   MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes(dim_in, dim_out) && mgcn::aligned16(wp_dev),
                "pack_weights: packed buffer too small or misaligned");
+  if (lockstep_shape(dim_in, dim_out)) return mgcn::fused2_pack(dim_in, dim_out, w_dev, wp_dev, stream);
   return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
 }
 
@@ -59,6 +67,15 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                            partial_dev, stream))
       return rc;
   }
+  // tune bits 10-11 = 3: the elastic kernel on a lockstep shape (A/B runs; the two packings coincide for O > 128 only)
+  const bool force3 = ((tune >> 10) & 3) == 3;
+  MGCN_REQUIRE(!force3 || dim_out > 128, "layer_fwd_fused: tune %d: the elastic kernel reads another packing for O <= 128", tune);
+  if (lockstep_shape(dim_in, dim_out) && !force3)
+    return mgcn::fused2_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
+                               loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
+                               bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
+                               num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
+                               want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, stream);
   return mgcn::fused3_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,

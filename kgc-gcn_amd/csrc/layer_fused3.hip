@@ -854,7 +854,7 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   auto fits = [&](int a, int b, bool r) { return lds_bytes3(s, a, b, nt, r ? rel_bytes : 0) <= LDS_MAX; };
   const bool rel_wanted = rel_bytes > 0 && rel_bytes <= size_t(32) * 1024 && t_rel != 1;
   if (t_nrt || t_img || t_nch) {
-    nrt = t_nrt ? t_nrt : nrt_cap;
+    nrt = t_nrt ? (t_nrt < nrt_cap ? t_nrt : nrt_cap) : nrt_cap;   // (a tile taller than the run is pointless)
     nimg = t_img ? t_img : 2;
     rel_lds = rel_wanted && fits(nrt, nimg, true);
     if (nrt < 3 || nrt > nrt_cap || nimg < 1 || nimg > 4 || !fits(nrt, nimg, rel_lds))

@@ -34,7 +34,20 @@ int launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_rows, co
                         const float *ee_dev, int32_t ee_in_slot_order, int64_t ee_sub_hub, const int32_t *chunks_dev,
                         int64_t chunk_begin, int64_t chunk_end, float *partial_dev, void *stream);
 
-// fused layer (layer_fused3.hip): one slot walk for 256 input columns, exact-width LDS buffers, a ring of staging buffers
+// fused layer, lockstep generation (layer_fused2.hip): D <= 256 and O <= 208 (the shapes whose alternating layers keep
+// the packed weights L2-resident only when every workgroup walks them in step)
+bool fused2_takes(int32_t dim_in, int32_t dim_out);
+size_t fused2_packed_bytes(int32_t dim_in, int32_t dim_out);
+int fused2_pack(int32_t dim_in, int32_t dim_out, const float *w_dev, void *wp_dev, void *stream);
+int fused2_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
+                  const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
+                  const float *loop_rel_dev, const float *ee_dev, const float *loop_edge_dev, const void *wp_dev,
+                  const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev, const float *bn_gamma_dev,
+                  const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
+                  int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
+                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, void *stream);
+
+// fused layer, elastic generation (layer_fused3.hip): one slot walk for 256 input columns, exact-width LDS buffers, a ring of staging buffers
 // coupled by LDS counters, one contiguous run of rows per workgroup
 bool fused3_takes(int32_t dim_in, int32_t dim_out);
 size_t fused3_packed_bytes(int32_t dim_in, int32_t dim_out);

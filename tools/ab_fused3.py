@@ -34,6 +34,8 @@ def main():
     x = (torch.randn(N, dims[0], generator=g) * 0.3).to(dev)
     rel = (torch.randn(2 * R, dims[0], generator=g) * 0.5).to(dev)
     res = {'shape': shape_name, 'zipf': zipf, 'layers': []}
+    cold_src = torch.empty(40 << 20, device=dev)          # 160 MB read + 160 MB written between two timed launches
+    cold_dst = torch.empty_like(cold_src)
     for li in range(len(dims) - 1):
         D, O = dims[li], dims[li + 1]
         layer = pkg.model.MGCNConv(D, O, 2 * R).to(dev).eval()
@@ -93,6 +95,15 @@ def main():
                 b.record()
                 torch.cuda.synchronize()
                 r['us'] = round(1e3 * a.elapsed_time(b) / K, 2)
+                if os.environ.get('AB_COLD'):     # as in the real step: the other layer's 120-200 MB pass through the caches in between
+                    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+                    for e0, e1 in evs:
+                        cold_dst.copy_(cold_src)
+                        e0.record()
+                        run()
+                        e1.record()
+                    torch.cuda.synchronize()
+                    r['us_cold'] = round(1e3 * sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs), 2)
                 if hasattr(nat.lib(), 'mgcn_diag_fused3') and (tune >> 10) & 3 == 3:   # diagnostics build: who waits for whom
                     import ctypes
                     import numpy as np
