@@ -15,7 +15,8 @@
  *     synchronises the device, so every call may be captured into a hipGraph;
  *   - return value 0 = MGCN_OK; otherwise an MGCN_E* code, and mgcn_last_error() returns a
  *     thread-local, human-readable message;
- *   - no global mutable state besides that thread-local error string; re-entrant per device;
+ *   - no global mutable state besides that thread-local error string (no cached device attributes, no environment
+ *     variables); re-entrant per device;
  *   - matrices are row-major f32, indices int32 on the device, int64 on the host side of the feeder.
  */
 #ifndef MGCN_HIP_H
@@ -189,13 +190,30 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
                            const float *bn_gamma_dev, const float *bn_beta_dev, float bn_eps,
                            float *out_dev, int64_t ldo, void *stream);
 
-/* (2)+(4) in ONE launch (eval mode): out = tanh(BN_eval((A_in W_in + A_out W_out + A_loop W_loop)/3 + bias)) with
- * the aggregates of (2) built per 32-destination tile in LDS by four gather waves and consumed by four MFMA waves of
- * the same block without ever reaching HBM. Arguments as in (2) and (4), except that the weights are passed in MFMA
- * fragment order: wp_dev = mgcn_pack_weights() of the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes
- * bytes, 16-byte aligned; re-pack whenever a weight changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all
- * operands are 16-byte aligned, ee_dev is given in slot order, dim_in % 4 == 0, dim_in <= 256, dim_out % 4 == 0 and
- * dim_out <= 208 — callers then use (2) followed by (4).
+/* (2)+(4) in ONE launch (eval mode): out = tanh(BN_eval((A_in W_in + A_out W_out + A_loop W_loop)/3 + bias)); the
+ * aggregates of (2) are built tile by tile in LDS and multiplied there, they never reach HBM. One 1024-thread workgroup
+ * per CU: eight waves gather (32-lane groups, 16 bytes per lane, a group sums its destinations' slots in slot order:
+ * the sums of (2)), eight waves multiply with v_mfma_f32_16x16x32_bf16 and run the epilogue on the accumulators. Two
+ * kernels sit behind this entry point, chosen by shape alone:
+ *   dim_in <= 256 and dim_out <= 208  csrc/layer_fused2.hip: tiles of 80 (or 64) destinations, stages of 128 input
+ *       columns, two LDS images, one workgroup barrier per stage;
+ *   otherwise (dim_in <= 1024, dim_out <= 512)  csrc/layer_fused3.hip: one contiguous run of rows per workgroup in
+ *       tiles of 48-80, stages of 128 or 256 columns, a ring of f32 staging buffers coupled by LDS counters, 13 or 32
+ *       column tiles.
+ * Arguments as in (2) and (4), except that the weights are passed in MFMA fragment order: wp_dev = mgcn_pack_weights() of
+ * the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes bytes, 16-byte aligned; re-pack whenever a weight
+ * changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all operands are 16-byte aligned, ee_dev is given in
+ * slot order, dim_in % 4 == 0, dim_in <= 1024, dim_out % 4 == 0 and dim_out <= 512 — callers then use (2) followed by (4).
+ * NUMERIC CONTRACT. The dense step is not the exact-f32 MFMA of (4): every aggregate a and weight w is split EXACTLY
+ * into three bf16 pieces (hi = bf16(v) rounded to nearest, mid = bf16(v - hi), lo = v - hi - mid; hi + mid + lo == v bit
+ * for bit) and the six products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid are accumulated in f32; the dropped terms
+ * are below 2^-26 |a||w| per product. For finite inputs |out - exact| <= 4 u B + 2e-7 with u = 2^-24 and
+ * B = sum_k |a_k||w_k| * |gamma| / (3 sqrt(var + eps)) (tests/test_gpu_round3.py holds both this launch and (2)+(4) to
+ * it on rows with 2^40 of dynamic range; on the benchmark's data both are within 5e-7 of float64). Results are
+ * bit-identical across launches of this entry point (whole graph, any destination range, any table shard, either
+ * generation's geometry for the same shape) but differ from (2)+(4) in the last bits (<= 2e-6 on a tanh output for
+ * dim_in <= 256). A non-finite input (inf / NaN) in a gathered row makes that destination's output row NaN, where
+ * (2)+(4) may return +-1; other rows are unaffected.
  * Destination partition: only destinations [node_begin, node_end) are computed; out_dev holds THOSE rows
  * (row 0 = node_begin). A rank may hold only its shard of the slot-ordered per-edge table — the rows of the in-half
  * slots [rowptr_in[node_begin], rowptr_in[node_end]) followed by those of the out-half slots of the same nodes — and
@@ -204,8 +222,12 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * table all three are 0. x_dev is always the whole [N, D] layer input.
  * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [chunk_end - chunk_begin, dim_in].
  * rel_out_dev (optional, [num_rel_rows - 1, dim_out]) = rel_dev @ rels_weight_dev [dim_in, dim_out] (model.py:107, the
- * relations the next layer / the scorer read) computed by a few extra workgroups of the same launch with the
- * arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed. */
+ * relations the next layer / the scorer read) computed by the gather waves of the same launch after their last stage,
+ * with the arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed.
+ * tune: 0 = automatic. For A/B runs of the layer_fused3.hip geometry only (never needed for correctness): bits 0-3 row
+ * tiles per tile (3..5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS (1 = never), bits 10-11 = 3 forces
+ * layer_fused3.hip on a shape of the other kernel (dim_out > 128 only), bits 12-13 input columns per slot walk (1 = 128,
+ * 2 = 256). */
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
@@ -277,6 +299,12 @@ int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t di
                     int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
                     const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
+/* The same counts from the generic tile kernel for every shape (mgcn_score_rank keeps aligned shapes with dim <= 256 on a
+ * kernel that holds the query strip in LDS): the two are bit-identical; this entry exists so that tests can say so. */
+int mgcn_score_rank_tiles(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                          int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                          const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                          const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
 
 /* Training loss fused with the scoring pass (replaces model.py:177-179 + model.py:42-44 and the
  * autograd of both down to the logits, main.py:61-66): for z[b, n] = x[b,:] . ent[n,:] + bias[n], p = sigmoid(z) and

@@ -883,10 +883,10 @@ extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row
   return launch<EPI_TARGET, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<TARGET>");
 }
 
-extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
-                               int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
-                               const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                               const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
+static int score_rank_impl(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                           int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                           const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                           const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, bool force_tile, void *stream) {
   if (int rc = check_common("score_rank", n_local, dim, batch)) return rc;
   MGCN_REQUIRE(x_dev && ent_dev && bias_dev && obj_dev && target_dev && counts_dev, "score_rank: null pointer");
   MGCN_REQUIRE((label_dev != nullptr) != (mask_dev != nullptr), "score_rank: give exactly one of label / mask");
@@ -902,25 +902,16 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
   p.m = n_local; p.k = dim; p.ncols = batch;
   set_vec_flags(&p);
   p.tiles_m = int32_t((p.m + BM - 1) / BM);
-  // MGCN_RANK_TILE=1 (read once) keeps every shape on the generic tile kernel: tests cover that path with it
-  static const bool force_tile = [] { const char *e = getenv("MGCN_RANK_TILE"); return e && e[0] == '1'; }();
   if (p.a_vec && p.b_vec && dim % 4 == 0 && dim <= RANK_MAX_KB * KS && !force_tile) {
     // aligned shapes with K <= 256: the query strip stays in LDS (rank_resident_kernel)
     const int nkb = (dim + KS - 1) / KS;
     const size_t lds = (size_t(nkb) * KS * (RANK_NT * 16 + 4) + size_t(RANK_NT) * 16 * 3) * sizeof(float);
-    // more than 64 KB of dynamic LDS needs an opt-in: done ONCE per device (the attribute is sticky), so the call
-    // itself stays free of runtime API work and capturable; a refusal sends every call to the tile kernel
-    static int lds_state[64] = {};   // 0 = not tried, 1 = granted, 2 = refused
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = (dev >= 0 && dev < 64) ? dev : 0;
-    if (lds_state[dev] == 0) {
-      const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-      if (!ok) (void)hipGetLastError();
-      lds_state[dev] = ok ? 1 : 2;
-    }
-    if (lds_state[dev] == 1) {
+    // more than 64 KB of dynamic LDS needs an opt-in (sticky per device; set on every call: no state is kept here); a
+    // refusal sends the call to the tile kernel
+    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    if (ok) {
       const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
       const int pairs = (p.tiles_m + 1) / 2;
       const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
@@ -930,5 +921,21 @@ extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0,
     }
   }
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
+}
+
+extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                               int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                               const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                               const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
+  return score_rank_impl(batch, n_local, ent_row0, dim, x_dev, ldx, ent_dev, lde, bias_dev, obj_dev, target_dev, label_dev, ldl,
+                         mask_dev, ldm, counts_dev, false, stream);
+}
+
+extern "C" int mgcn_score_rank_tiles(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                                     int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                                     const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
+  return score_rank_impl(batch, n_local, ent_row0, dim, x_dev, ldx, ent_dev, lde, bias_dev, obj_dev, target_dev, label_dev, ldl,
+                         mask_dev, ldm, counts_dev, true, stream);
 }
 

@@ -99,7 +99,7 @@ class _LayerTrainFn(torch.autograd.Function):
 
 
 class _ScoreFn(torch.autograd.Function):
-    """sigmoid(x @ ent^T + bias): forward on the HIP tile kernel, backward as three plain GEMMs."""
+    """sigmoid(x @ ent^T + bias): forward and both backward products on the HIP f32 MFMA tile kernel."""
 
     @staticmethod
     def forward(ctx, x, ent, bias):
@@ -110,15 +110,16 @@ class _ScoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gs):
         x, ent, s = ctx.saved_tensors
-        gz = gs * s * (1.0 - s)
-        return (gz @ ent if ctx.needs_input_grad[0] else None,
-                gz.t() @ x if ctx.needs_input_grad[1] else None,
+        gz = (gs * s * (1.0 - s)).contiguous()
+        return (_native.matmul(gz, ent.contiguous()) if ctx.needs_input_grad[0] else None,
+                _native.matmul(gz.t().contiguous(), x.contiguous()) if ctx.needs_input_grad[1] else None,
                 gz.sum(0) if ctx.needs_input_grad[2] else None)
 
 
 class _ScoreBCEFn(torch.autograd.Function):
     """mean BCE(sigmoid(x @ ent^T + bias), targets) in ONE launch: the scores and the [B, N] targets are
-    never materialised; the launch leaves d loss / d logits [N, B], the backward is two plain GEMMs and a row sum."""
+    never materialised; the launch leaves d loss / d logits [N, B], the backward is two products on the HIP MFMA kernels
+    (G x on the tile kernel, G^T ent on the split-K transposed kernel) and a row sum."""
 
     @staticmethod
     def forward(ctx, x, ent, bias, mask, hot, cold):
@@ -129,7 +130,11 @@ class _ScoreBCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         x, ent, g = ctx.saved_tensors
-        return ((g.t() @ ent) * gl if ctx.needs_input_grad[0] else None,
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = (_native.matmul_tn(g, ent.contiguous()) if _native.matmul_tn_supported(g.size(1), ent.size(1))
+                  else _native.matmul(g.t().contiguous(), ent.contiguous())) * gl
+        return (gx,
                 _native.matmul(g, x) * gl if ctx.needs_input_grad[1] else None,
                 g.sum(1) * gl if ctx.needs_input_grad[2] else None, None, None, None)
 

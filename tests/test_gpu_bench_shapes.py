@@ -1,7 +1,7 @@
 """Parity on EXACTLY what bench.py times (VERDICT r1 "Next round" item 1): the 2-layer 100 -> 200 -> 200 encoder at
 the full WN18RR / FB15k-237 shapes (so the D = 200 instance of the fused layer kernel and its sharded form run under
 test), and score + filter + count at N = 40 943 / 14 541, B = 128, O = 200 (the strip loop of rank_resident_kernel,
-the generic tile kernel with MGCN_RANK_TILE=1 and with an unaligned O). Float tolerances are written at each assert;
+the generic tile kernel through mgcn_score_rank_tiles and with an unaligned O). Float tolerances are written at each assert;
 integer results are compared with torch.equal."""
 import os
 import subprocess
@@ -176,17 +176,15 @@ def test_full_size_rank_unaligned_width_takes_tile_kernel(pkg, oracle):
 
 
 def test_rank_tile_kernel_forced_equals_resident(pkg, oracle):
-    """MGCN_RANK_TILE=1 (read once per process, so a child process): the generic tile kernel on the aligned full-size
-    shape returns the same integer counts as rank_resident_kernel."""
+    """mgcn_score_rank_tiles (the generic tile kernel on every shape) returns the same integer counts as the LDS-resident
+    rank kernel on the aligned full-size shape, with the dense-label and with the bit-mask filter."""
     want = _check_rank(pkg, oracle, 40943, 128, 200, seed=5)
-    code = ('import sys, torch; sys.path.insert(0, %r); from tests.test_gpu_bench_shapes import _check_rank; '
-            'import importlib; pkg = importlib.import_module("kgc-gcn_amd"); '
-            'oracle = importlib.import_module("oracle.mgcn_oracle"); '
-            'c = _check_rank(pkg, oracle, 40943, 128, 200, seed=5); torch.save(c, sys.argv[1])' % ROOT)
-    out = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'mgcn_rank_tile_counts.pt')
-    env = dict(os.environ, MGCN_RANK_TILE='1')
-    subprocess.run([sys.executable, '-c', code, out], check=True, env=env, cwd=ROOT, timeout=600)
-    assert torch.equal(torch.load(out, weights_only=True), want)
+    nat = pkg._native
+    x, ent, bias, obj, label = _rank_case(40943, 128, 200, 5)
+    xd, ed, bd, od, ld = (t.to(DEV) for t in (x, ent, bias, obj, label))
+    target = nat.score_target(xd, ed, bd, od)
+    assert torch.equal(nat.score_rank(xd, ed, bd, od, target, label=ld, force_tile=True).cpu(), want)
+    assert torch.equal(nat.score_rank(xd, ed, bd, od, target, label=ld).cpu(), want)
 
 
 def test_sharded_and_dense_evaluation_agree_on_the_same_queries(pkg, oracle):
