@@ -277,7 +277,12 @@ int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_dev, int64_t
  *   score[b, n] = sigmoid( x[b,:] . ent[n,:] + bias[n] ),  x [B, O], ent [n_local, O].
  * mgcn_score_fwd materialises score [B, n_local] (training / the drop-in forward()).
  * mgcn_score_target computes target[b] = score[b, obj[b]] for the queries whose obj lies in
- *   [ent_row0, ent_row0 + n_local) with the SAME arithmetic as the tile kernels (others untouched).
+ *   [ent_row0, ent_row0 + n_local) with the SAME arithmetic as the other two (others untouched).
+ * One arithmetic for all three, chosen by shape alone: 16-byte aligned operands with dim % 4 == 0 and dim <= 352 take the
+ *   six-product bf16 split on the bf16 MFMA (exact three-way split of both operands, f32 accumulation: the numeric
+ *   contract of (2)+(4) in one launch below; 6/16 of the exact-f32 MFMA's time); other shapes the exact-f32 MFMA. A score
+ *   is the same f32 value whichever of the three entry points computes it, so counts are exact against a recount over
+ *   mgcn_score_fwd's scores.
  * mgcn_score_rank never materialises the scores: for every b it adds to counts[b, 0..2]
  *   gt   = #{n != obj[b], not filtered : score[b,n] >  target[b]}
  *   tl   = #{n != obj[b], not filtered, n <  obj[b] : score[b,n] == target[b]}   (ties_lower)
@@ -299,13 +304,6 @@ int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t di
                     int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
                     const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
-/* The same counts from the generic tile kernel for every shape (mgcn_score_rank keeps aligned shapes with dim <= 256 on a
- * kernel that holds the query strip in LDS): the two are bit-identical; this entry exists so that tests can say so. */
-int mgcn_score_rank_tiles(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
-                          int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
-                          const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                          const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream);
-
 /* Training loss fused with the scoring pass (replaces model.py:177-179 + model.py:42-44 and the
  * autograd of both down to the logits, main.py:61-66): for z[b, n] = x[b,:] . ent[n,:] + bias[n], p = sigmoid(z) and
  * targets y[b, n] = hot where bit n of mask[b] is set, cold elsewhere (mgcn_filter_mask over the TRAIN index; hot / cold

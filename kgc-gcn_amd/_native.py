@@ -44,8 +44,6 @@ _SIGNATURES = {
     'mgcn_score_target': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr]),
     'mgcn_score_rank': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
                                        _ptr, _i64, _ptr, _ptr]),
-    'mgcn_score_rank_tiles': (ctypes.c_int, [_i32, _i64, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64,
-                                             _ptr, _i64, _ptr, _ptr]),
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_bce_partials': (_i64, [_i32, _i64]),
     'mgcn_score_bce_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr,
@@ -464,10 +462,9 @@ def score_target(x, ent, bias, obj, ent_row0=0, out=None):
     return out
 
 
-def score_rank(x, ent, bias, obj, target, label=None, ent_row0=0, counts=None, mask=None, force_tile=False):
+def score_rank(x, ent, bias, obj, target, label=None, ent_row0=0, counts=None, mask=None):
     """counts [B, 3] int64 += (gt, ties_lower, ties) over this shard's entities. Filter = dense `label` rows [B, n]
-    (reference loader) or the bit-packed `mask` [B, ceil(n/32)] int32 from filter_mask(). `force_tile`: the generic tile
-    kernel also where the LDS-resident one would run (mgcn_score_rank_tiles; bit-identical counts, for tests)."""
+    (reference loader) or the bit-packed `mask` [B, ceil(n/32)] int32 from filter_mask()."""
     B, n, O = _score_args(x, ent, bias)
     if (label is None) == (mask is None):
         raise NativeError('score_rank: give exactly one of label / mask')
@@ -480,8 +477,7 @@ def score_rank(x, ent, bias, obj, target, label=None, ent_row0=0, counts=None, m
     if counts is None:
         counts = torch.zeros((B, 3), dtype=torch.int64, device=x.device)
     _same_device(x, ent, bias, obj, target, label, mask, counts)
-    entry = lib().mgcn_score_rank_tiles if force_tile else lib().mgcn_score_rank
-    _check(entry(B, n, int(ent_row0), O, _dev(x, torch.float32, 'x'), _ld(x),
+    _check(lib().mgcn_score_rank(B, n, int(ent_row0), O, _dev(x, torch.float32, 'x'), _ld(x),
                                  _dev(ent, torch.float32, 'ent'), _ld(ent), _dev(bias, torch.float32, 'bias'),
                                  _dev(obj, torch.int64, 'obj'), _dev(target, torch.float32, 'target'),
                                  _dev(label, torch.float32, 'label', True), _ld(label) if label is not None else 0,

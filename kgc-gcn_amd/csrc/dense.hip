@@ -6,6 +6,8 @@
 //   EPI_TARGET    target[b]   = score[b, obj[b]]  (same tile arithmetic, gathered rows, diagonal)
 //   EPI_RANK      filtered counts gt / ties_lower / ties per query, scores never stored (main.py:122-126)
 //   EPI_BCE       training: BCE(sigmoid(score), target) partial sums + d loss / d logit [M, ncols] (main.py:61-66, N3)
+// and, for aligned scoring shapes with K <= 352, score_split_kernel<SIGMOID / TARGET / RANK>: the same three results on
+// the bf16 MFMA from exactly split operands (below).
 //
 // Geometry. The streamed operand (aggregates [N,3D], or the entity table [N,O]) is always the MFMA A
 // operand and goes global -> registers directly: lane (r = l&15, q = l>>4) loads the 16 bytes
@@ -474,159 +476,250 @@ __global__ __launch_bounds__(THREADS, min_waves(EPI, NT)) void tile_kernel(TileA
   }
 }
 
-// RANK with the query block RESIDENT in LDS (main.py:122-126 for up to 128 queries per strip): the tile kernel
-// re-stages the [K, 128] query slabs for every 32-entity row tile (131 MB of L2 -> LDS traffic and a transposing
-// ds_write pass per k-block for one WN18RR batch); here a 512-thread block transposes its strip of x into LDS once
-// and its two half-blocks (four waves each, the tile kernel's wave layout) walk the entity row tiles, streaming only
-// the entity rows (one dwordx4 per lane and k-block, the next tile's rows in flight under the current tile's MFMAs).
-// Same k grouping per MFMA step, same accumulation order and the same sigmoid as tile_kernel, so scores — and
-// therefore counts — are bit-identical to the other scoring kernels.
-constexpr int RANK_NT = 8, RANK_MAX_KB = 16;   // 128 queries per strip, K <= 256
-__global__ __launch_bounds__(512, 2) void rank_resident_kernel(TileArgs p) {
-  constexpr int NT = RANK_NT, BNC = NT * 16, LDB = BNC + 4, NTW = NT / 2;
-  extern __shared__ __attribute__((aligned(16))) float Bs[];   // [nkb * 16][LDB], then 3 * BNC counters
-  const int nkb = (p.k + KS - 1) / KS, kpad = nkb * KS;
-  unsigned int *cnt = reinterpret_cast<unsigned int *>(Bs + kpad * LDB);
+// ---------------------------------------------------------------------------------------------------------------
+// Scoring on the bf16 MFMA (round 3): score / target / filtered rank counts for ALIGNED shapes with K <= 352 — the
+// shapes of every evaluation of the benchmark. One kernel, three epilogues, ONE arithmetic: every entity value a and
+// query value x is split exactly into three bf16 pieces (hi = bf16(v) rounded, mid = bf16(v - hi), lo = v - hi - mid;
+// the split of layer_fused3.hip) and a score is the f32 sum over k-blocks of 32 of the six products
+// (a_hi x_lo) (a_lo x_hi) (a_mid x_mid) (a_hi x_mid) (a_mid x_hi) (a_hi x_hi) on v_mfma_f32_16x16x32_bf16 — 6/16 of the
+// exact-f32 MFMA's pipe time, everything down to 2^-26 |a||x| per product kept. The order is fixed and does not depend
+// on the tile, the strip or the epilogue, so a score computed by SIGMOID, TARGET and RANK is the same f32 value and
+// counts stay exact against a recount over the materialised scores. Unaligned shapes and K > 352 keep the exact-f32
+// tile kernels for all three entry points alike.
+// Block = 512 threads, a strip of 64 queries resident in LDS as three bf16 pieces laid out [piece][k-block][8-k group]
+// [query][16 B] (a lane's B fragment of a column tile is one conflict-free ds_read_b128); each wave walks 16-entity
+// row tiles: 32 bytes of the entity row per lane and k-block straight from global (the next k-block's in flight),
+// split in registers (18 VALU per 8 values), 4 column tiles x 6 MFMAs.
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3p_(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+  h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2s{v0, v1}, bf16x2s));
+  const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+  m = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2s{r0, r1}, bf16x2s));
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2s{s0, s1}, bf16x2s));
+}
+__device__ __forceinline__ void split8_(const float4 &lo, const float4 &hi, u32x4s &h, u32x4s &m, u32x4s &l) {
+  uint32_t a, b, c;
+  split3p_(lo.x, lo.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
+  split3p_(lo.z, lo.w, a, b, c); h[1] = a; m[1] = b; l[1] = c;
+  split3p_(hi.x, hi.y, a, b, c); h[2] = a; m[2] = b; l[2] = c;
+  split3p_(hi.z, hi.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
+}
+constexpr int SS_NQT = 4, SS_BQ = SS_NQT * 16, SS_MAX_KB = 11, SS_THREADS = 512;   // 64 queries per strip, K <= 352
+
+template <int EPI>
+__global__ __launch_bounds__(SS_THREADS, 2) void score_split_kernel(TileArgs p) {
+  constexpr int NQT = SS_NQT, BQ = SS_BQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ss[];
+  const int nkb = (p.k + 31) >> 5;
+  const int piece = nkb * 4 * BQ * 16;
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(ss + 3 * piece);   // RANK: [BQ][3]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int half = wave >> 2, w4 = wave & 3, rt = w4 & 1, ch = w4 >> 1, ct0 = ch * NTW;
   const int fr = lane & 15, fq = lane >> 4;
-  const int c0 = int(blockIdx.y) * BNC;
-  // x strip -> Bs[k][query] (k rows past K are zero; queries past the batch repeat the last one, never counted)
-  // lane -> (16 queries) x (4 k-quads): 64-byte global pieces per query row, two-way LDS bank conflicts at most
-  const int kq4 = kpad / 4, kq4p = (kq4 + 3) / 4 * 4;
-  for (int idx = tid; idx < (BNC / 16) * (kq4p / 4) * 64; idx += 512) {
-    const int grp = idx >> 6, l = idx & 63;
-    const int c = (grp % (BNC / 16)) * 16 + (l & 15), kk = ((grp / (BNC / 16)) * 4 + (l >> 4)) * 4;
-    if (kk >= kpad) continue;
-    int col = c0 + c;
-    col = col < p.ncols ? col : p.ncols - 1;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kk < p.k) v = *reinterpret_cast<const float4 *>(p.b + int64_t(col) * p.ldb + kk);
-    Bs[(kk + 0) * LDB + c] = v.x;
-    Bs[(kk + 1) * LDB + c] = v.y;
-    Bs[(kk + 2) * LDB + c] = v.z;
-    Bs[(kk + 3) * LDB + c] = v.w;
+  const int c0 = int(blockIdx.y) * BQ;
+  // the strip's queries -> LDS, split: item = (8-k group, query); consecutive threads take consecutive queries
+  for (int it = tid; it < nkb * 4 * BQ; it += SS_THREADS) {
+    const int q = it % BQ, kg = it / BQ, k0 = 8 * kg;
+    int col = c0 + q;
+    col = col < p.ncols ? col : p.ncols - 1;       // queries past the batch repeat the last one, never stored or counted
+    const float *src = p.b + int64_t(col) * p.ldb + k0;
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (k0 < p.k) lo = *reinterpret_cast<const float4 *>(src);
+    if (k0 + 4 < p.k) hi = *reinterpret_cast<const float4 *>(src + 4);
+    u32x4s h, m, l;
+    split8_(lo, hi, h, m, l);
+    unsigned char *dst = ss + (kg * BQ + q) * 16;
+    *reinterpret_cast<u32x4s *>(dst) = h;
+    *reinterpret_cast<u32x4s *>(dst + piece) = m;
+    *reinterpret_cast<u32x4s *>(dst + 2 * piece) = l;
   }
-  for (int i = tid; i < BNC * 3; i += 512) cnt[i] = 0;
+  if (EPI == EPI_RANK) {
+    for (int i = tid; i < BQ * 3; i += SS_THREADS) cnt[i] = 0;
+  }
   __syncthreads();
 
-  unsigned int my_gt[NTW], my_tl[NTW], my_ti[NTW];
-  float tgt[NTW];
-  int64_t ob[NTW];
+  unsigned int my_gt[NQT], my_tl[NQT], my_ti[NQT];
+  float tgt[NQT];
+  int64_t ob[NQT];
+  if (EPI == EPI_RANK) {
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    my_gt[t] = my_tl[t] = my_ti[t] = 0;
-    int col = c0 + (ct0 + t) * 16 + fr;
-    col = col < p.ncols ? col : p.ncols - 1;
-    tgt[t] = p.target[col];
-    ob[t] = p.obj[col] - p.row0;
-  }
-  auto aload = [&](float4 (&a)[RANK_MAX_KB], int tm) {
-    int64_t arow = int64_t(tm) * BM + rt * 16 + fr;
-    arow = arow < p.m ? arow : p.m - 1;                 // rows past M are computed from a valid row and never counted
-    const float *ap = p.a + arow * p.lda + 4 * fq;
-#pragma unroll
-    for (int kb = 0; kb < RANK_MAX_KB; ++kb) {
-      a[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kb < nkb && kb * KS + 4 * fq < p.k) a[kb] = *reinterpret_cast<const float4 *>(ap + kb * KS);
-    }
-  };
-  // the tile's filter words (its 32 rows are one 32-bit word per query) and entity biases travel with the A rows
-  auto eload = [&](uint32_t (&mw)[NTW], float (&bv)[4], int tm) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      int col = c0 + (ct0 + t) * 16 + fr;
+    for (int t = 0; t < NQT; ++t) {
+      my_gt[t] = my_tl[t] = my_ti[t] = 0;
+      int col = c0 + t * 16 + fr;
       col = col < p.ncols ? col : p.ncols - 1;
-      mw[t] = p.mask ? p.mask[int64_t(col) * p.ldl + tm] : 0u;
+      tgt[t] = p.target[col];
+      ob[t] = p.obj[col] - p.row0;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int64_t row = int64_t(tm) * BM + rt * 16 + fq * 4 + j;
-      row = row < p.m ? row : p.m - 1;
-      bv[j] = p.bias[row];
-    }
-  };
-  float4 a_cur[RANK_MAX_KB], a_nxt[RANK_MAX_KB];
-  uint32_t m_cur[NTW], m_nxt[NTW];
-  float b_cur[4], b_nxt[4];
-  const int step = int(gridDim.x) * 2;
-  int tm = int(blockIdx.x) * 2 + half;
-  if (tm < p.tiles_m) {
-    aload(a_cur, tm);
-    eload(m_cur, b_cur, tm);
   }
-  for (; tm < p.tiles_m; tm += step) {
-    if (tm + step < p.tiles_m) {
-      aload(a_nxt, tm + step);
-      eload(m_nxt, b_nxt, tm + step);
+  const int tiles16 = int((p.m + 15) >> 4);
+  // A wave takes PAIRS of 16-entity row tiles (32 rows = one filter word per query): the query fragments it reads from LDS
+  // feed both tiles' MFMAs, and 48 MFMAs per k-block cover the latency of the next k-block's row loads.
+  // TARGET: row i is query i's target entity and only the diagonal is wanted: row tile (strip, t) meets column tile t.
+  constexpr int RT = EPI == EPI_TARGET ? 1 : 2;
+  const int units = EPI == EPI_TARGET ? tiles16 : (tiles16 + 1) >> 1;
+  int tu = EPI == EPI_TARGET ? int(blockIdx.y) * NQT + wave : int(blockIdx.x) * 8 + wave;
+  const int step = EPI == EPI_TARGET ? units : int(gridDim.x) * 8;
+  if (EPI == EPI_TARGET && wave >= NQT) tu = units;
+  for (; tu < units; tu += step) {
+    const float *ap[RT];
+    bool a_ok[RT];
+#pragma unroll
+    for (int h = 0; h < RT; ++h) {
+      int64_t arow = (int64_t(tu) * RT + h) * 16 + fr;
+      a_ok[h] = true;
+      if (EPI == EPI_TARGET) {
+        a_ok[h] = arow < p.m;
+        if (a_ok[h]) {
+          const int64_t o = p.obj[arow] - p.row0;    // the entity row query `arow` must be scored against
+          a_ok[h] = o >= 0 && o < p.n_local;
+          arow = o;
+        }
+      } else {
+        arow = arow < p.m ? arow : p.m - 1;          // rows past M: a valid row, never stored or counted
+      }
+      ap[h] = p.a + (a_ok[h] ? arow : 0) * p.lda + 8 * fq;
     }
-    f32x4 acc[NTW];
+    auto aload = [&](float4 (&lo)[RT], float4 (&hi)[RT], int kb) {
+      const int k0 = 32 * kb + 8 * fq;
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < RT; ++h) {
+        lo[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hi[h] = lo[h];
+        if (a_ok[h] && k0 < p.k) lo[h] = *reinterpret_cast<const float4 *>(ap[h] + 32 * kb);
+        if (a_ok[h] && k0 + 4 < p.k) hi[h] = *reinterpret_cast<const float4 *>(ap[h] + 32 * kb + 4);
+      }
+    };
+    f32x4 acc[RT][NQT];
 #pragma unroll
-    for (int kb = 0; kb < RANK_MAX_KB; ++kb) {
-      if (kb < nkb) {
-        const float *bs = Bs + (kb * KS + 4 * fq) * LDB + ct0 * 16 + fr;
-        const float av[4] = {a_cur[kb].x, a_cur[kb].y, a_cur[kb].z, a_cur[kb].w};
-        float bf[2][NTW];
+    for (int h = 0; h < RT; ++h) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) bf[0][t] = bs[t * 16];
+      for (int t = 0; t < NQT; ++t) acc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float4 alo[RT], ahi[RT], nlo[RT], nhi[RT];
+    aload(alo, ahi, 0);
+    uint32_t mw[NQT];
+    float bv[RT][4];
+    if (EPI == EPI_RANK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i + 1 < 4) {
+      for (int t = 0; t < NQT; ++t) {
+        int col = c0 + t * 16 + fr;
+        col = col < p.ncols ? col : p.ncols - 1;
+        mw[t] = p.mask ? p.mask[int64_t(col) * p.ldl + tu] : 0u;   // the pair's 32 rows = one filter word of the query
+      }
+    }
+    if (EPI == EPI_RANK || EPI == EPI_SIGMOID) {
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) bf[(i + 1) & 1][t] = bs[(i + 1) * LDB + t * 16];
+      for (int h = 0; h < RT; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int64_t row = (int64_t(tu) * RT + h) * 16 + fq * 4 + j;
+          row = row < p.m ? row : p.m - 1;
+          bv[h][j] = p.bias[row];
+        }
+      }
+    }
+    for (int kb = 0; kb < nkb; ++kb) {
+      if (kb + 1 < nkb) aload(nlo, nhi, kb + 1);
+      u32x4s ah[RT], am[RT], al[RT];
+#pragma unroll
+      for (int h = 0; h < RT; ++h) split8_(alo[h], ahi[h], ah[h], am[h], al[h]);
+      const unsigned char *bp = ss + ((kb * 4 + fq) * BQ + fr) * 16;
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        if (EPI == EPI_TARGET && t != wave) continue;
+        const bf16x8s bh = __builtin_bit_cast(bf16x8s, *reinterpret_cast<const u32x4s *>(bp + t * 256));
+        const bf16x8s bm = __builtin_bit_cast(bf16x8s, *reinterpret_cast<const u32x4s *>(bp + piece + t * 256));
+        const bf16x8s bl = __builtin_bit_cast(bf16x8s, *reinterpret_cast<const u32x4s *>(bp + 2 * piece + t * 256));
+#pragma unroll
+        for (int h = 0; h < RT; ++h) {
+          f32x4 c = acc[h][t];   // the six products, small terms first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, ah[h]), bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, al[h]), bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, am[h]), bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, ah[h]), bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, am[h]), bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8s, ah[h]), bh, c, 0, 0, 0);
+          acc[h][t] = c;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < RT; ++h) {
+        alo[h] = nlo[h];
+        ahi[h] = nhi[h];
+      }
+    }
+    // lane holds entities (RT tu + h) * 16 + 4 fq + j (j = 0..3) of query column c0 + 16 t + fr
+#pragma unroll
+    for (int h = 0; h < RT; ++h) {
+      const int64_t r0 = (int64_t(tu) * RT + h) * 16 + fq * 4;
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const int col = c0 + t * 16 + fr;
+        if (col >= p.ncols) continue;
+        if (EPI == EPI_SIGMOID) {
+          float sc[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sc[j] = sigmoidf_(acc[h][t][j] + bv[h][j]);
+          float *dst = p.c + int64_t(col) * p.ldc + r0;
+          if (r0 + 3 < p.m && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 15u) == 0) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (r0 + j < p.m) dst[j] = sc[j];
           }
+        } else if (EPI == EPI_TARGET) {
+          if (t != wave) continue;
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bf[i & 1][t], acc[t], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            const int64_t row = r0 + j;                 // query index of this accumulator row
+            if (row == col && row < p.m) {
+              const int64_t o = p.obj[row] - p.row0;
+              if (o >= 0 && o < p.n_local) p.target_out[row] = sigmoidf_(acc[h][t][j] + p.bias[o]);
+            }
+          }
+        } else if (EPI == EPI_RANK) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t row = r0 + j;
+            if (row >= p.m || row == ob[t]) continue;                          // the target itself (main.py:125)
+            if (p.mask) {
+              if ((mw[t] >> (h * 16 + fq * 4 + j)) & 1u) continue;
+            } else {
+              const float lab = p.label[int64_t(col) * p.ldl + row];
+              if ((static_cast<int>(lab) & 0xff) != 0) continue;                // label.byte() filter (main.py:124)
+            }
+            const float sc = sigmoidf_(acc[h][t][j] + bv[h][j]);
+            my_gt[t] += sc > tgt[t];
+            const bool eq = sc == tgt[t];
+            my_ti[t] += eq;
+            my_tl[t] += eq && (row < ob[t]);
+          }
         }
       }
     }
-    const int64_t r0 = int64_t(tm) * BM;
+  }
+  if (EPI == EPI_RANK) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = c0 + (ct0 + t) * 16 + fr;
-      if (col >= p.ncols) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t row = r0 + rt * 16 + fq * 4 + j;
-        if (row >= p.m || row == ob[t]) continue;                          // the target itself (main.py:125)
-        if (p.mask) {
-          if ((m_cur[t] >> (rt * 16 + fq * 4 + j)) & 1u) continue;          // BM = 32 rows = one filter word
-        } else {
-          const float lab = p.label[int64_t(col) * p.ldl + row];
-          if ((static_cast<int>(lab) & 0xff) != 0) continue;                // label.byte() filter (main.py:124)
-        }
-        const float sc = sigmoidf_(acc[t][j] + b_cur[j]);
-        my_gt[t] += sc > tgt[t];
-        const bool eq = sc == tgt[t];
-        my_ti[t] += eq;
-        my_tl[t] += eq && (row < ob[t]);
+    for (int t = 0; t < NQT; ++t) {
+      unsigned int g = my_gt[t], l = my_tl[t], e = my_ti[t];
+      g += __shfl_xor(g, 16); l += __shfl_xor(l, 16); e += __shfl_xor(e, 16);
+      g += __shfl_xor(g, 32); l += __shfl_xor(l, 32); e += __shfl_xor(e, 32);
+      if (fq == 0) {
+        atomicAdd(&cnt[(t * 16 + fr) * 3 + 0], g);
+        atomicAdd(&cnt[(t * 16 + fr) * 3 + 1], l);
+        atomicAdd(&cnt[(t * 16 + fr) * 3 + 2], e);
       }
     }
-#pragma unroll
-    for (int kb = 0; kb < RANK_MAX_KB; ++kb) a_cur[kb] = a_nxt[kb];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) m_cur[t] = m_nxt[t];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b_cur[j] = b_nxt[j];
-  }
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    unsigned int g = my_gt[t], l = my_tl[t], e = my_ti[t];
-    g += __shfl_xor(g, 16); l += __shfl_xor(l, 16); e += __shfl_xor(e, 16);
-    g += __shfl_xor(g, 32); l += __shfl_xor(l, 32); e += __shfl_xor(e, 32);
-    if (fq == 0) {
-      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 0], g);
-      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 1], l);
-      atomicAdd(&cnt[((ct0 + t) * 16 + fr) * 3 + 2], e);
+    __syncthreads();
+    for (int i = tid; i < BQ * 3; i += SS_THREADS) {
+      const int col = c0 + i / 3;
+      if (col < p.ncols && cnt[i]) atomicAdd(&p.counts[int64_t(col) * 3 + i % 3], (unsigned long long)cnt[i]);
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < BNC * 3; i += 512) {
-    const int col = c0 + i / 3;
-    if (col < p.ncols && cnt[i]) atomicAdd(&p.counts[int64_t(col) * 3 + i % 3], (unsigned long long)cnt[i]);
   }
 }
 
@@ -822,6 +915,32 @@ extern "C" int mgcn_label_rows(int32_t batch, const int64_t *qkey_dev, int64_t n
   return MGCN_OK;
 }
 
+// Aligned scoring shapes take score_split_kernel (one arithmetic for score / target / rank counts); the rest keep the
+// exact-f32 tile kernels — the SAME choice for all three entry points, so their results stay mutually consistent.
+bool split_scoring(TileArgs *p) {
+  set_vec_flags(p);
+  return p->a_vec && p->b_vec && p->k % 4 == 0 && p->k <= SS_MAX_KB * 32;
+}
+
+template <int EPI>
+int launch_split(const TileArgs &p, hipStream_t stream, const char *name) {
+  const int nkb = (p.k + 31) / 32;
+  const size_t lds = size_t(3) * nkb * 4 * SS_BQ * 16 + size_t(SS_BQ) * 3 * sizeof(unsigned int);
+  // more than 64 KB of dynamic LDS needs an opt-in (sticky per device; set on every call: no state is kept here)
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(score_split_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024) != hipSuccess)
+    return mgcn::fail(MGCN_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
+  const unsigned gy = unsigned((p.ncols + SS_BQ - 1) / SS_BQ);
+  const int64_t tiles16 = (p.m + 15) / 16;
+  int64_t gx = 512 / gy;                                  // at most 512 blocks of 8 waves: two even rounds on 256 CUs
+  const int64_t cap = ((tiles16 + 1) / 2 + 7) / 8;        // (a wave takes pairs of row tiles)
+  gx = gx < cap ? gx : cap;
+  if (EPI == EPI_TARGET || gx < 1) gx = 1;
+  hipLaunchKernelGGL(score_split_kernel<EPI>, dim3(unsigned(gx), gy), dim3(SS_THREADS), lds, stream, p);
+  MGCN_CHECK_LAUNCH(name);
+  return MGCN_OK;
+}
+
 extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const float *x_dev, int64_t ldx,
                               const float *ent_dev, int64_t lde, const float *bias_dev, float *score_dev,
                               int64_t lds, void *stream) {
@@ -835,6 +954,7 @@ extern "C" int mgcn_score_fwd(int32_t batch, int64_t n_local, int32_t dim, const
   p.c = score_dev; p.ldc = lds;
   p.bias = bias_dev;
   p.m = n_local; p.k = dim; p.ncols = batch;
+  if (split_scoring(&p)) return launch_split<EPI_SIGMOID>(p, static_cast<hipStream_t>(stream), "score_split_kernel<SIGMOID>");
   return launch<EPI_SIGMOID, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<SIGMOID>");
 }
 
@@ -880,13 +1000,14 @@ extern "C" int mgcn_score_target(int32_t batch, int64_t n_local, int64_t ent_row
   p.n_local = n_local;
   p.bias = bias_dev; p.obj = obj_dev; p.target_out = target_dev; p.row0 = ent_row0;
   p.m = batch; p.k = dim; p.ncols = batch;
+  if (split_scoring(&p)) return launch_split<EPI_TARGET>(p, static_cast<hipStream_t>(stream), "score_split_kernel<TARGET>");
   return launch<EPI_TARGET, true>(p, 0, static_cast<hipStream_t>(stream), "tile_kernel<TARGET>");
 }
 
-static int score_rank_impl(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
-                           int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
-                           const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                           const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, bool force_tile, void *stream) {
+extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
+                               int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
+                               const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
+                               const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
   if (int rc = check_common("score_rank", n_local, dim, batch)) return rc;
   MGCN_REQUIRE(x_dev && ent_dev && bias_dev && obj_dev && target_dev && counts_dev, "score_rank: null pointer");
   MGCN_REQUIRE((label_dev != nullptr) != (mask_dev != nullptr), "score_rank: give exactly one of label / mask");
@@ -900,42 +1021,8 @@ static int score_rank_impl(int32_t batch, int64_t n_local, int64_t ent_row0, int
   p.ldl = label_dev ? ldl : ldm;
   p.counts = reinterpret_cast<unsigned long long *>(counts_dev); p.row0 = ent_row0;
   p.m = n_local; p.k = dim; p.ncols = batch;
-  set_vec_flags(&p);
+  if (split_scoring(&p)) return launch_split<EPI_RANK>(p, static_cast<hipStream_t>(stream), "score_split_kernel<RANK>");
   p.tiles_m = int32_t((p.m + BM - 1) / BM);
-  if (p.a_vec && p.b_vec && dim % 4 == 0 && dim <= RANK_MAX_KB * KS && !force_tile) {
-    // aligned shapes with K <= 256: the query strip stays in LDS (rank_resident_kernel)
-    const int nkb = (dim + KS - 1) / KS;
-    const size_t lds = (size_t(nkb) * KS * (RANK_NT * 16 + 4) + size_t(RANK_NT) * 16 * 3) * sizeof(float);
-    // more than 64 KB of dynamic LDS needs an opt-in (sticky per device; set on every call: no state is kept here); a
-    // refusal sends the call to the tile kernel
-    const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(rank_resident_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    if (!ok) (void)hipGetLastError();
-    if (ok) {
-      const unsigned gy = unsigned((batch + RANK_NT * 16 - 1) / (RANK_NT * 16));
-      const int pairs = (p.tiles_m + 1) / 2;
-      const unsigned gx = unsigned(pairs < 256 ? pairs : 256);
-      hipLaunchKernelGGL(rank_resident_kernel, dim3(gx, gy), dim3(512), lds, static_cast<hipStream_t>(stream), p);
-      MGCN_CHECK_LAUNCH("rank_resident_kernel");
-      return MGCN_OK;
-    }
-  }
   return launch<EPI_RANK, true>(p, 1280, static_cast<hipStream_t>(stream), "tile_kernel<RANK>");
-}
-
-extern "C" int mgcn_score_rank(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
-                               int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
-                               const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                               const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
-  return score_rank_impl(batch, n_local, ent_row0, dim, x_dev, ldx, ent_dev, lde, bias_dev, obj_dev, target_dev, label_dev, ldl,
-                         mask_dev, ldm, counts_dev, false, stream);
-}
-
-extern "C" int mgcn_score_rank_tiles(int32_t batch, int64_t n_local, int64_t ent_row0, int32_t dim, const float *x_dev,
-                                     int64_t ldx, const float *ent_dev, int64_t lde, const float *bias_dev,
-                                     const int64_t *obj_dev, const float *target_dev, const float *label_dev, int64_t ldl,
-                                     const uint32_t *mask_dev, int64_t ldm, int64_t *counts_dev, void *stream) {
-  return score_rank_impl(batch, n_local, ent_row0, dim, x_dev, ldx, ent_dev, lde, bias_dev, obj_dev, target_dev, label_dev, ldl,
-                         mask_dev, ldm, counts_dev, true, stream);
 }
 

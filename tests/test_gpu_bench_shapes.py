@@ -1,7 +1,7 @@
 """Parity on EXACTLY what bench.py times (VERDICT r1 "Next round" item 1): the 2-layer 100 -> 200 -> 200 encoder at
 the full WN18RR / FB15k-237 shapes (so the D = 200 instance of the fused layer kernel and its sharded form run under
-test), and score + filter + count at N = 40 943 / 14 541, B = 128, O = 200 (the strip loop of rank_resident_kernel,
-the generic tile kernel through mgcn_score_rank_tiles and with an unaligned O). Float tolerances are written at each assert;
+test), and score + filter + count at N = 40 943 / 14 541, B = 128, O = 200 (score_split_kernel: many row-tile pairs per wave,
+the exact-f32 tile kernels with an unaligned and with a wide O). Float tolerances are written at each assert;
 integer results are compared with torch.equal."""
 import os
 import subprocess
@@ -166,7 +166,7 @@ def _check_rank(pkg, oracle, N, B, O, seed=3):
 
 @pytest.mark.parametrize('N', [40943, 14541])
 def test_full_size_rank_counts(pkg, oracle, N):
-    """N = 40 943 is 640 row-tile pairs > the 256-workgroup grid of rank_resident_kernel: its strip loop runs."""
+    """N = 40 943 is 1 280 row-tile pairs for a 256 x 8-wave grid: the waves' pair loop of score_split_kernel runs."""
     _check_rank(pkg, oracle, N, 128, 200)
 
 
@@ -175,16 +175,11 @@ def test_full_size_rank_unaligned_width_takes_tile_kernel(pkg, oracle):
     _check_rank(pkg, oracle, 14541, 128, 198)
 
 
-def test_rank_tile_kernel_forced_equals_resident(pkg, oracle):
-    """mgcn_score_rank_tiles (the generic tile kernel on every shape) returns the same integer counts as the LDS-resident
-    rank kernel on the aligned full-size shape, with the dense-label and with the bit-mask filter."""
-    want = _check_rank(pkg, oracle, 40943, 128, 200, seed=5)
-    nat = pkg._native
-    x, ent, bias, obj, label = _rank_case(40943, 128, 200, 5)
-    xd, ed, bd, od, ld = (t.to(DEV) for t in (x, ent, bias, obj, label))
-    target = nat.score_target(xd, ed, bd, od)
-    assert torch.equal(nat.score_rank(xd, ed, bd, od, target, label=ld, force_tile=True).cpu(), want)
-    assert torch.equal(nat.score_rank(xd, ed, bd, od, target, label=ld).cpu(), want)
+def test_full_size_rank_wide_embedding_takes_tile_kernel(pkg, oracle):
+    """O = 384 > 352: past the LDS strip of the bf16-split scoring kernel, all three entry points take the exact-f32 tile
+    kernels; O = 352 is the widest shape of the split kernel."""
+    _check_rank(pkg, oracle, 14541, 128, 384, seed=6)
+    _check_rank(pkg, oracle, 14541, 128, 352, seed=7)
 
 
 def test_sharded_and_dense_evaluation_agree_on_the_same_queries(pkg, oracle):
