@@ -60,15 +60,19 @@ class _LayerTrainFn(torch.autograd.Function):
         d = w_in.size(0)
         u_in, u_out = _native.matmul(agg[:, :d], w_in.contiguous()), _native.matmul(agg[:, d:], w_out.contiguous())
         u_loop = _native.matmul(a_loop.contiguous(), w_loop.contiguous())
+        # dropout keep-masks are saved as bool (1 byte per element, not a scaled f32 copy) and scaled by 1 / keep at use
         m_in = m_out = None
+        ctx.inv_keep = 1.0
         if p_drop >= 1.0:                       # F.dropout(p=1) is all zeros (1 / keep would be 0 / 0)
-            m_in, m_out = torch.zeros_like(u_in), torch.zeros_like(u_out)
-            u_in, u_out = m_in, m_out
+            m_in = torch.zeros(u_in.shape, dtype=torch.bool, device=u_in.device)
+            m_out, ctx.inv_keep = m_in, 0.0
+            u_in, u_out = torch.zeros_like(u_in), torch.zeros_like(u_out)
         elif p_drop > 0:
             keep = 1.0 - p_drop
-            m_in = torch.empty_like(u_in).bernoulli_(keep).div_(keep)
-            m_out = torch.empty_like(u_out).bernoulli_(keep).div_(keep)
-            u_in, u_out = u_in * m_in, u_out * m_out
+            ctx.inv_keep = 1.0 / keep
+            m_in = torch.empty_like(u_in).bernoulli_(keep).bool()
+            m_out = torch.empty_like(u_out).bernoulli_(keep).bool()
+            u_in, u_out = (u_in * m_in).mul_(ctx.inv_keep), (u_out * m_out).mul_(ctx.inv_keep)   # as F.dropout: x * mask * (1 / keep)
         y, z, mean, rstd = _native.bn_tanh_train_fwd(u_in, u_out, u_loop, bias, gamma, beta, running_mean, running_var,
                                                      momentum, eps)
         ctx.save_for_backward(agg, a_loop, w_in, w_out, w_loop, gamma, z, y, mean, rstd, m_in, m_out)
@@ -80,8 +84,8 @@ class _LayerTrainFn(torch.autograd.Function):
         agg, a_loop, w_in, w_out, w_loop, gamma, z, y, mean, rstd, m_in, m_out = ctx.saved_tensors
         d = w_in.size(0)
         gz, gu, ggamma, gbeta = _native.bn_tanh_train_bwd(z, y, gy, mean, rstd, gamma)
-        g_in = gu * m_in if m_in is not None else gu
-        g_out = gu * m_out if m_out is not None else gu
+        g_in = (gu * m_in).mul_(ctx.inv_keep) if m_in is not None else gu
+        g_out = (gu * m_out).mul_(ctx.inv_keep) if m_out is not None else gu
         need = ctx.needs_input_grad
         g_agg = g_loop = g_win = g_wout = g_wloop = None
         if need[0]:
