@@ -62,7 +62,8 @@ def main():
             for tune in tunes:
                 nat.FUSED_TUNE = tune
                 wpack = nat.pack_weights(wcat)
-                out = torch.full((N, O), float('nan'), device=dev)
+                ldo = int(os.environ.get('AB_LDO', O))          # padded output rows (row stride in floats)
+                out = torch.full((N, ldo), float('nan'), device=dev)[:, :O]
                 rel_out = torch.empty((2 * R, O), device=dev)
 
                 def run():
