@@ -139,14 +139,18 @@ int mgcn_csr_build_host(int64_t num_nodes, int64_t num_edges_half, int64_t num_r
  * can be pipelined against (4) on another stream, and a destination partition is one rank's share.
  * Hubs: [chunk_begin, chunk_end) are the chunks of the hubs among [node_begin, node_end) — one run, because the hub
  * region is in node order (all chunks for the whole graph). When it is not empty (hubinfo_dev / chunks_dev from the
- * feeder) the chunk sums are first written to partial_dev [chunk_end - chunk_begin, D] by a pre-pass launch on the
- * same stream, a second launch folds every hub's chunk sums into the row of its first chunk, and the main launch
- * adds that one row per hub.
+ * feeder) ONE pre-pass launch on the same stream writes the chunk sums to partial_dev [chunk_end - chunk_begin, D] and
+ * folds every hub's chunk sums into the row of its first chunk (the last lane group to arrive at a hub's counter adds the
+ * rows up in row order: a fixed summation tree), and the main launch adds that one row per hub. partial_dev holds
+ * mgcn_hub_partial_floats(chunk_end - chunk_begin, D) floats: the rows, then 2 * (chunk_end - chunk_begin) int32 arrival
+ * counters which must be ZERO before the first launch that uses the buffer; every completed launch leaves them zero, so a
+ * buffer can be reused by later launches on the same stream without clearing (not by launches that may overlap).
  * Table shard (ABI 2): as in the fused launch below, ee_dev may hold only the rows a destination range needs — its
  * in-half slots, its out-half slots, its hub slots, each a contiguous run — with ee_sub_in / ee_sub_out / ee_sub_hub such
  * that the row of (absolute) slot s is s - ee_sub_{region}; all three are 0 with the whole table. This is what lets a
  * rank of the destination partition hold 1/W of a table that does not fit one GPU (configs[4]: 410 GB).
  */
+int64_t mgcn_hub_partial_floats(int64_t num_chunks, int32_t dim);
 int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,
                        const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev, const float *x_dev,
                        int64_t ldx, const float *rel_dev, const float *loop_rel_dev, const float *ee_dev,
@@ -220,7 +224,8 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * then the hub slots [chunks[chunk_begin].begin, chunks[chunk_end - 1].end) of the same nodes — and passes
  * ee_sub_in / ee_sub_out / ee_sub_hub such that the row of (absolute) slot s is s - ee_sub_{region}; with the whole
  * table all three are 0. x_dev is always the whole [N, D] layer input.
- * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [chunk_end - chunk_begin, dim_in].
+ * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [mgcn_hub_partial_floats(chunk_end -
+ * chunk_begin, dim_in)] with its counters zero (one pre-pass launch before the layer's launch).
  * rel_out_dev (optional, [num_rel_rows - 1, dim_out]) = rel_dev @ rels_weight_dev [dim_in, dim_out] (model.py:107, the
  * relations the next layer / the scorer read) computed by the gather waves of the same launch after their last stage,
  * with the arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed.

@@ -46,6 +46,7 @@ _SIGNATURES = {
                                        _ptr, _i64, _ptr, _ptr]),
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_bce_partials': (_i64, [_i32, _i64]),
+    'mgcn_hub_partial_floats': (_i64, [_i64, _i32]),
     'mgcn_score_bce_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr,
                                           _i64, _ptr, _ptr]),
     'mgcn_label_rows': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
@@ -157,13 +158,27 @@ def csr_build_host(num_nodes, num_rel_rows, edge_index, edge_type, with_backward
 
 
 def _hub_args(csr, d, device, n0, n1):
-    """(hubinfo ptr, chunks ptr, chunk_begin, chunk_end, partial tensor) for a launch over destinations [n0, n1):
-    chunk sums live in a per-call buffer."""
+    """(hubinfo ptr, chunks ptr, chunk_begin, chunk_end, partial tensor) for a launch over destinations [n0, n1). The chunk
+    sums and the fold's arrival counters live in a buffer kept on the graph per (width, chunk range): the counters are
+    zero when it is made and every launch leaves them zero (include/mgcn_hip.h (2)), and its address is stable for a
+    captured launch. Launches that share it must not overlap: a launch on another stream than the last one waits for
+    that stream first."""
     c0, c1 = csr.chunk_range(n0, n1)
     if c1 == c0:
         return None, None, 0, 0, None
-    partial = torch.empty((c1 - c0, d), dtype=torch.float32, device=device)
-    return _dev(csr.hubinfo, torch.int32, 'hubinfo'), _dev(csr.chunks, torch.int32, 'chunks'), c0, c1, partial
+    cache = csr.__dict__.setdefault('_hub_partials', {})
+    key = (int(d), c0, c1, str(device))
+    hit = cache.get(key)
+    stream = torch.cuda.current_stream(device)
+    if hit is None:
+        if len(cache) >= 16:
+            cache.clear()
+        hit = cache[key] = [torch.zeros(int(lib().mgcn_hub_partial_floats(c1 - c0, int(d))), dtype=torch.float32, device=device),
+                            stream]
+    elif hit[1] != stream and not torch.cuda.is_current_stream_capturing():
+        stream.wait_stream(hit[1])
+        hit[1] = stream
+    return _dev(csr.hubinfo, torch.int32, 'hubinfo'), _dev(csr.chunks, torch.int32, 'chunks'), c0, c1, hit[0]
 
 
 def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None, ee_sub=(0, 0, 0),

@@ -22,6 +22,15 @@ struct Vec<4> {
   static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
   static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
   static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+  // agent-scope accesses (write-through / cache-bypassing: coherent across the XCDs' L2s inside a launch)
+  static __device__ __forceinline__ float4 load_agent(const float *p) {
+    return make_float4(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  static __device__ __forceinline__ void store_agent(float *p, float4 v) {
+    __hip_atomic_store(p, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(p + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(p + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   static __device__ __forceinline__ float4 mul(float4 a, float4 b) {
     return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
   }
@@ -38,6 +47,8 @@ struct Vec<1> {
   static __device__ __forceinline__ float zero() { return 0.f; }
   static __device__ __forceinline__ float load(const float *p) { return *p; }
   static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+  static __device__ __forceinline__ float load_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  static __device__ __forceinline__ void store_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   static __device__ __forceinline__ float mul(float a, float b) { return a * b; }
   static __device__ __forceinline__ float muls(float a, float s) { return a * s; }
   static __device__ __forceinline__ float add(float a, float b) { return a + b; }
@@ -58,6 +69,7 @@ struct AggArgs {
   const int2 *hubinfo;   // [2][N] (first chunk, chunk count) or null
   const int4 *chunks;    // [num_chunks] {slot begin, slot end, first chunk of the hub, chunks of the hub}
   float *partial;        // [num_chunks][D] chunk sums; after the fold, row `first chunk` holds the hub's total
+  int32_t *hubcnt;       // [2][num_chunks] arrival counters of the fold (zero between launches), index = chunk - chunk0
   int32_t chunk0, nchunks;  // chunks [chunk0, chunk0 + nchunks) are in play; partial row = chunk - chunk0
   int64_t ee_sub_hub;       // table row of hub slot s = s - ee_sub_hub (slot-ordered table shards)
   int64_t ee_sub[2];        // ... and of a slot of half h: s - ee_sub[h] (0 with the whole table)
@@ -153,9 +165,64 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   }
 }
 
-// Hub pre-pass: one lane group per chunk of a hub destination's slots; same arithmetic and slot order as above.
-template <int VEC, int CPL, int U>
-__global__ __launch_bounds__(256) void agg_hub_kernel(AggArgs p, int gs_log2) {
+constexpr int kFoldSpan = 16;
+
+// The hub fold inside the pre-pass launch. A group that has stored its row arrives at a counter; the LAST group to arrive (whichever it
+// is) adds the rows up in row order, so the summation tree depends only on the hub's chunk count: spans of kFoldSpan chunk sums into the
+// span's first row, then the span totals (stride kFoldSpan) into the hub's first row. The XCDs' L2s are not coherent with each other
+// inside a launch, and agent-scope fences (L2 write-back + invalidate per group) double the launch's time by evicting the gathered rows;
+// so the chunk-sum rows themselves are written and read with agent-scope accesses (write-through stores, cache-bypassing loads), a
+// group waits for its stores to be acknowledged before its (memory-side) counter increment, and the last arriver's loads depend on the
+// increment's result. The last arriver puts the counter back to zero for the next launch.
+__device__ __forceinline__ bool hub_arrive(int32_t *counter, int expected, int lane_in_group, int gs) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // s_waitcnt vmcnt(0): this group's row stores are acknowledged
+  int old = 0;
+  if (lane_in_group == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __shfl(old, 0, gs);
+  if (old != expected - 1) return false;
+  if (lane_in_group == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (compiler ordering: the row loads stay behind the increment)
+  return true;
+}
+
+template <int VEC, int CPL>
+__device__ __forceinline__ void hub_fold_rows(float *rows, int count, int64_t rstride, const int (&col)[CPL], int lane_in_group, int gs,
+                                              int nchunk) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  constexpr int UF = 16 / CPL > 0 ? 16 / CPL : 1;
+  T tot[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) tot[c] = V::load_agent(rows + col[c]);
+  for (int k = 1; k < count; k += UF) {
+    T v[UF][CPL];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int kk = min(k + u, count - 1);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) v[u][c] = V::load_agent(rows + int64_t(kk) * rstride + col[c]);
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (k + u < count) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) tot[c] = V::add(tot[c], v[u][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c)
+    if (lane_in_group + c * gs < nchunk) V::store_agent(rows + col[c], tot[c]);
+}
+
+// Hub pre-pass: one lane group per chunk of a hub destination's slots; same arithmetic and slot order as above. A chunk is a chain
+// of dependent round trips for its group (there are few groups: ~4 waves per CU on the FB15k-237 shape), so the chain is kept short:
+// the group's lanes fetch 2 * GS records with two loads up front and hand them round by lane shuffles, and the rows of batch b + 1 are
+// in flight while batch b is added up (two register sets). The loop body is free of branches around loads (slot index clamped to the
+// chunk's last slot, column clamped to the row's last chunk, the relation / self-loop row chosen by offset; only the adds are
+// predicated), so the compiler counts the outstanding loads instead of draining them.
+template <int VEC, int CPL, int U, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void agg_hub_kernel(AggArgs p, int gs_log2) {
   using V = Vec<VEC>;
   using T = typename V::type;
   const int gs = 1 << gs_log2;
@@ -164,60 +231,91 @@ __global__ __launch_bounds__(256) void agg_hub_kernel(AggArgs p, int gs_log2) {
   if (chunk >= p.nchunks) return;
   const int nchunk = p.d / VEC;
   const int4 range = p.chunks[p.chunk0 + chunk];
+  const int end = range.y, last = end - 1;
+  int col[CPL];                                   // this lane's columns (clamped: lanes past the row load its last chunk and store nothing)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) col[c] = min(lane_in_group + c * gs, nchunk - 1) * VEC;
+  const int64_t loop_off = p.loop_rel - p.rel;    // the self-loop row as an offset from the relation table
+  const float *ee = p.ee ? p.ee : p.x;            // no per-edge table: a valid address, the value is not used
+  const bool has_ee = p.ee != nullptr;
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-  for (int s = range.x; s < range.y; s += U) {
-    int4 r[U];
+  for (int beg = range.x; beg < end; beg += 2 * gs) {        // (one pass unless the graph was built with chunks of more than 2 * GS slots)
+    const int stop = min(beg + 2 * gs, end);
+    const int nb = (stop - beg + U - 1) / U;
+    const int4 win0 = p.rec[min(beg + lane_in_group, last)], win1 = p.rec[min(beg + gs + lane_in_group, last)];
+    T xa[U][CPL], ra[U][CPL], ea[U][CPL], xb[U][CPL], rb[U][CPL], eb[U][CPL];
+    float wa[U], wb[U];
+    auto issue = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (s + u < range.y) r[u] = p.rec[s + u];
-    T xv[U][CPL], rv[U][CPL], ev[U][CPL];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (s + u >= range.y) continue;
-      const float *xr = p.x + int64_t(r[u].x) * p.ldx;
-      const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
-      const float *er = p.ee ? p.ee + (p.ee_slot_order ? int64_t(s + u) - p.ee_sub_hub : int64_t(r[u].w)) * p.d : nullptr;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int ch = lane_in_group + c * gs;
-        if (ch < nchunk) {
-          xv[u][c] = V::load(xr + ch * VEC);
-          rv[u][c] = V::load(rr + ch * VEC);
-          if (er) ev[u][c] = V::load(er + ch * VEC);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (s + u < range.y) {
-        const float w = __int_as_float(r[u].z);
+      for (int u = 0; u < U; ++u) {
+        const int s = min(beg + b * U + u, last);
+        const int idx = min(s - beg, 2 * gs - 1);
+        const bool hi = idx >= gs;
+        int4 r;
+        r.x = __shfl(hi ? win1.x : win0.x, idx, gs); r.y = __shfl(hi ? win1.y : win0.y, idx, gs);
+        r.z = __shfl(hi ? win1.z : win0.z, idx, gs); r.w = __shfl(hi ? win1.w : win0.w, idx, gs);
+        wt[u] = __int_as_float(r.z);
+        const float *xr = p.x + int64_t(r.x) * p.ldx;
+        const float *rr = p.rel + ((r.y < p.rel_rows - 1) ? int64_t(r.y) * p.d : loop_off);
+        const float *er = ee + (has_ee ? (p.ee_slot_order ? int64_t(s) - p.ee_sub_hub : int64_t(r.w)) * p.d : int64_t(0));
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-          const int ch = lane_in_group + c * gs;
-          if (ch < nchunk) {
+          xv[u][c] = V::load(xr + col[c]);
+          rv[u][c] = V::load(rr + col[c]);
+          ev[u][c] = V::load(er + col[c]);
+        }
+      }
+    };
+    auto consume = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (beg + b * U + u < stop) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
             T m = V::mul(xv[u][c], rv[u][c]);
-            if (p.ee) m = V::mul(m, ev[u][c]);
-            acc[c] = V::add(acc[c], V::muls(m, w));
+            if (has_ee) m = V::mul(m, ev[u][c]);
+            acc[c] = V::add(acc[c], V::muls(m, wt[u]));
           }
         }
       }
+    };
+    issue(xa, ra, ea, wa, 0);
+    for (int b = 0; b < nb; b += 2) {
+      issue(xb, rb, eb, wb, b + 1);
+      consume(xa, ra, ea, wa, b);
+      issue(xa, ra, ea, wa, b + 2);
+      consume(xb, rb, eb, wb, b + 1);
     }
   }
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lane_in_group + c * gs;
-    if (ch < nchunk) V::store(p.partial + chunk * p.d + ch * VEC, acc[c]);
+    if (ch < nchunk) V::store_agent(p.partial + chunk * p.d + ch * VEC, acc[c]);
+  }
+  const int w = range.w;                                         // chunks of this hub (the same for a group's lanes)
+  if (w < 2) return;
+  const int hub0 = range.z - p.chunk0;                           // row of the hub's first chunk
+  const int j0 = int(chunk) - hub0;                              // this chunk's index inside its hub
+  float *hub_rows = p.partial + int64_t(hub0) * p.d;
+  if (w > kFoldSpan) {
+    const int sp0 = j0 - j0 % kFoldSpan, spn = min(kFoldSpan, w - sp0);
+    if (!hub_arrive(p.hubcnt + hub0 + sp0, spn, lane_in_group, gs)) return;
+    hub_fold_rows<VEC, CPL>(hub_rows + int64_t(sp0) * p.d, spn, p.d, col, lane_in_group, gs, nchunk);
+    if (!hub_arrive(p.hubcnt + p.nchunks + hub0, (w + kFoldSpan - 1) / kFoldSpan, lane_in_group, gs)) return;
+    hub_fold_rows<VEC, CPL>(hub_rows, (w + kFoldSpan - 1) / kFoldSpan, int64_t(kFoldSpan) * p.d, col, lane_in_group, gs, nchunk);
+  } else {
+    if (!hub_arrive(p.hubcnt + p.nchunks + hub0, w, lane_in_group, gs)) return;
+    hub_fold_rows<VEC, CPL>(hub_rows, w, p.d, col, lane_in_group, gs, nchunk);
   }
 }
 
-// Hub fold, two levels (a hub of thousands of slots has hundreds of chunk sums: one workgroup adding them all is a chain of
+// Hub fold as launches of its own (the backward pre-pass of gx uses it), two levels (a hub of thousands of slots has hundreds of chunk sums: one workgroup adding them all is a chain of
 // dependent round trips). Level 1 (span = kFoldSpan, stride = 1): the workgroup of every kFoldSpan-th chunk of a hub adds
 // the next kFoldSpan chunk sums into its own row. Level 2 (stride = kFoldSpan): the workgroup of the hub's FIRST chunk adds
 // those rows into the first. Lane group j adds rows j, j+J, j+2J, ... of its span in that order (U loads in flight), then
 // group 0 adds the J group sums in group order: a fixed summation tree that depends only on the hub's chunk count.
-constexpr int kFoldSpan = 16;
 struct FoldArgs {
   const int4 *chunks;
   float *partial;
@@ -672,6 +770,7 @@ int mgcn::launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_ro
   p.ldx = ldx; p.n = int32_t(num_nodes); p.d = dim; p.rel_rows = num_rel_rows; p.ee_slot_order = ee_in_slot_order;
   p.chunks = reinterpret_cast<const int4 *>(chunks_dev);
   p.partial = partial_dev;
+  p.hubcnt = reinterpret_cast<int32_t *>(partial_dev + num_chunks * dim);
   p.chunk0 = int32_t(chunk_begin);
   p.nchunks = int32_t(num_chunks);
   p.ee_sub_hub = ee_sub_hub;
@@ -696,9 +795,11 @@ int mgcn::launch_hub_partials(int64_t num_nodes, int32_t dim, int32_t num_rel_ro
   }
 #undef MGCN_HUB_CASE
   MGCN_CHECK_LAUNCH("agg_hub_kernel");
-  launch_fold(g, p.chunks, p.partial, p.chunk0, dim, num_chunks, st);
-  MGCN_CHECK_LAUNCH("agg_hub_fold_kernel");
   return MGCN_OK;
+}
+
+extern "C" int64_t mgcn_hub_partial_floats(int64_t num_chunks, int32_t dim) {
+  return num_chunks > 0 && dim > 0 ? num_chunks * dim + 2 * num_chunks : 0;
 }
 
 extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int32_t dim, int32_t num_rel_rows,

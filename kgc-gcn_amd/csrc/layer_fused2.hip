@@ -54,7 +54,7 @@ struct Args2 {
   float bn_eps;
 #ifdef MGCN_DIAG
   unsigned long long *stamps;   // [grid][2 roles][128]: s_memtime at stage starts / ends of wave 0 (multiply) and wave 4 (gather)
-  int32_t ablate;   // diagnostics build only (tools/ab_fused2.py): bit 0 no slots gathered, bit 1 no MFMAs, bit 2 no epilogue
+  int32_t ablate;   // diagnostics build only (tools/fused_ablate.py, tools/ablate_device_time.sh): bit 0 no slots gathered, bit 1 no MFMAs, bit 2 no epilogue
 #endif
 };
 #ifdef MGCN_DIAG

@@ -205,3 +205,49 @@ def test_fused_dense_step_on_adversarial_rows(pkg, oracle):
     touched[dst[src == 17]] = True
     assert torch.equal(poisoned[~touched], fused[~touched])
     assert not torch.isfinite(poisoned[17]).all()
+
+
+@pytest.mark.parametrize('D', [100, 200, 36])
+def test_hub_fold_inside_the_prepass_launch(pkg, oracle, D):
+    """The hub pre-pass is ONE launch (chunk sums + the two-level fold by the last lane group to arrive at a hub's counter,
+    include/mgcn_hip.h (2)): a Zipf graph whose top hubs have more than 16 chunks (both fold levels) and hubs of 2..16
+    chunks (one level). The aggregate matches a float64 scatter-add of the same messages (model.py:111-118), two launches
+    are bit-identical (the fold order does not depend on which group arrives last), the arrival counters are zero again
+    after every launch, and a destination range gives the rows of the full launch."""
+    N, R, E = 3000, 7, 60000
+    ei, ea, csr = _graph(pkg, oracle, N, R, E, seed=5, zipf=1.3, hub_threshold=16, hub_chunk=8)
+    chunks = csr.chunks.cpu().numpy().reshape(-1, 4)[:csr.num_chunks]
+    assert chunks[:, 3].max() > 16 and (chunks[:, 3] <= 16).any() and csr.num_chunks > 100
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(N, D, generator=g) * 0.5).to(DEV)
+    rel = (torch.randn(2 * R + 1, D, generator=g) * 0.5).to(DEV)
+    table = (torch.randn(2 * E, D, generator=g) * 0.5).to(DEV)            # slot order
+    loop_edge = torch.ones(D, device=DEV)
+    nat = pkg._native
+    out = torch.empty((N, 3 * D), device=DEV)
+    nat.aggregate_fwd(csr, x, rel, table, True, loop_edge, out)
+    again = torch.empty_like(out)
+    nat.aggregate_fwd(csr, x, rel, table, True, loop_edge, again)
+    assert torch.equal(out, again)
+    (buf, _), = [v for k, v in csr._hub_partials.items() if k[0] == D]
+    counters = buf[csr.num_chunks * D:].view(torch.int32)
+    assert counters.numel() == 2 * csr.num_chunks and int(counters.abs().max()) == 0
+    # float64 reference of the two edge halves in slot order
+    rec = csr.rec.cpu().numpy().reshape(-1, 4)
+    src, typ, norm = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64), rec[:, 2].copy().view(np.float32).astype(np.float64)
+    sd = csr.slot_dst.cpu().numpy().view(np.uint32).astype(np.int64)      # bit 31 = half (csr_build.cpp), hub slots included
+    dst, half = sd & 0x7fffffff, sd >> 31
+    msg = x.cpu().double().numpy()[src] * rel.cpu().double().numpy()[typ] * table.cpu().double().numpy() * norm[:, None]
+    want, mag = np.zeros((2, N, D)), np.zeros((2, N, D))
+    for h in range(2):
+        np.add.at(want[h], dst[half == h], msg[half == h])
+        np.add.at(mag[h], dst[half == h], np.abs(msg[half == h]))
+    got = out.cpu().double().numpy()
+    for h in range(2):
+        err = np.abs(got[:, h * D:(h + 1) * D] - want[h])
+        assert (err <= 256 * 2.0 ** -24 * mag[h] + 1e-30).all(), (h, float(err.max()))   # (a sequential f32 sum of n terms: (n - 1) u)
+    n0, n1 = 700, 2100
+    part = torch.empty((n1 - n0, 3 * D), device=DEV)
+    nat.aggregate_fwd(csr, x, rel, csr.edge_table_shard(table, n0, n1), True, loop_edge, part, node_range=(n0, n1),
+                      ee_sub=csr.shard_ee_sub(n0, n1), out_row0=n0)
+    assert torch.equal(part, out[n0:n1])

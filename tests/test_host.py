@@ -493,6 +493,7 @@ def test_abi_argument_validation_without_a_gpu(pkg):
     assert lib.mgcn_packed_weights_bytes(200, 200) == 3 * 7 * 13 * 3 * 64 * 16   # ceil(200 / 32) = 7 k-blocks per mode
     assert lib.mgcn_aggregate_bwd_workspace(10, 4, 3, 2) == (2 + 3 + 2) * 4 * 4      # ceil(20/16) chunks + rows + hub chunks
     assert lib.mgcn_score_bce_partials(128, 40943) == 1280
+    assert lib.mgcn_hub_partial_floats(10, 100) == 10 * 100 + 2 * 10 and lib.mgcn_hub_partial_floats(0, 100) == 0
 
 
 def test_chunkwise_xavier_table_rows(pkg):
