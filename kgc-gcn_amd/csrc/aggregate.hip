@@ -75,10 +75,81 @@ struct AggArgs {
   int64_t ee_sub[2];        // ... and of a slot of half h: s - ee_sub[h] (0 with the whole table)
 };
 
-// GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots in flight per group:
-// all of a batch's record loads are issued first, then all 3*U row loads, then the arithmetic, so a
-// short segment (WN18RR: 2.1 slots on average) costs three dependent memory round trips in total.
-template <int VEC, int CPL, int U>
+// The slot walk both forward kernels share: acc += sum over slots [first, end) of (x[src] * rel[type] [* ee[slot]]) * norm, in slot
+// order, by one lane group. The group's lanes fetch 2 * GS records with two loads and hand them round by lane shuffles; the rows of
+// batch b + 1 are in flight while batch b is added up (two register sets). The loop body is free of branches around loads (slot index
+// clamped to the run's last slot, column clamped to the row's last chunk, the relation / self-loop row chosen by offset; only the adds
+// are predicated), so the compiler counts the outstanding loads (`vmcnt(N)`) instead of draining them at every merge of two paths.
+template <int VEC, int CPL, int U, bool ROLL>
+__device__ __forceinline__ void walk_slots(const AggArgs &p, int first, int end, int64_t ee_sub, const int (&col)[CPL],
+                                           int lane_in_group, int gs, typename Vec<VEC>::type (&acc)[CPL]) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  const int last = end - 1;
+  const int64_t loop_off = p.loop_rel - p.rel;    // the self-loop row as an offset from the relation table
+  const float *ee = p.ee ? p.ee : p.x;            // no per-edge table: a valid address, the value is not used
+  const bool has_ee = p.ee != nullptr;
+  for (int beg = first; beg < end; beg += 2 * gs) {
+    const int stop = min(beg + 2 * gs, end);
+    const int nb = (stop - beg + U - 1) / U;
+    const int4 win0 = p.rec[min(beg + lane_in_group, last)], win1 = p.rec[min(beg + gs + lane_in_group, last)];
+    T xa[U][CPL], ra[U][CPL], ea[U][CPL], xb[U][CPL], rb[U][CPL], eb[U][CPL];
+    float wa[U], wb[U];
+    auto issue = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = min(beg + b * U + u, last);
+        const int idx = min(s - beg, 2 * gs - 1);
+        const bool hi = idx >= gs;
+        int4 r;
+        r.x = __shfl(hi ? win1.x : win0.x, idx, gs); r.y = __shfl(hi ? win1.y : win0.y, idx, gs);
+        r.z = __shfl(hi ? win1.z : win0.z, idx, gs); r.w = __shfl(hi ? win1.w : win0.w, idx, gs);
+        wt[u] = __int_as_float(r.z);
+        const float *xr = p.x + int64_t(r.x) * p.ldx;
+        const float *rr = p.rel + ((r.y < p.rel_rows - 1) ? int64_t(r.y) * p.d : loop_off);
+        const float *er = ee + (has_ee ? (p.ee_slot_order ? int64_t(s) - ee_sub : int64_t(r.w)) * p.d : int64_t(0));
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          xv[u][c] = V::load(xr + col[c]);
+          rv[u][c] = V::load(rr + col[c]);
+          ev[u][c] = V::load(er + col[c]);
+        }
+      }
+    };
+    auto consume = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (beg + b * U + u < stop) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            T m = V::mul(xv[u][c], rv[u][c]);
+            if (has_ee) m = V::mul(m, ev[u][c]);
+            acc[c] = V::add(acc[c], V::muls(m, wt[u]));
+          }
+        }
+      }
+    };
+    if (ROLL) {     // long runs: the next batch's rows are in flight while this one is added up
+      issue(xa, ra, ea, wa, 0);
+      for (int b = 0; b < nb; b += 2) {
+        issue(xb, rb, eb, wb, b + 1);
+        consume(xa, ra, ea, wa, b);
+        issue(xa, ra, ea, wa, b + 2);
+        consume(xb, rb, eb, wb, b + 1);
+      }
+    } else {        // short runs (a batch or two): no loads past the run's last batch, fewer registers, more waves per SIMD
+      for (int b = 0; b < nb; ++b) {
+        issue(xa, ra, ea, wa, b);
+        consume(xa, ra, ea, wa, b);
+      }
+    }
+  }
+}
+
+// GS lanes per group (power of two <= 64), CPL column chunks per lane, U slots per batch (two batches in flight per group): one group
+// per (mode, destination); a short run (WN18RR: 2.1 slots on average) costs three dependent memory round trips in total — row
+// pointers, records, rows.
+template <int VEC, int CPL, int U, bool ROLL = false>
 __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
   using V = Vec<VEC>;
   using T = typename V::type;
@@ -102,60 +173,19 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(AggArgs p, int gs_log2) {
     return;
   }
 
+  int col[CPL];                                   // this lane's columns (clamped: lanes past the row load its last chunk and store nothing)
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) col[c] = min(lane_in_group + c * gs, nchunk - 1) * VEC;
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
   const int32_t *rp = p.rowptr + int64_t(mode) * (p.n + 1);   // absolute slot positions
-  const int beg = rp[node], end = rp[node + 1];
-  const int64_t base = 0;
-  const int64_t ee_sub_mode = p.ee_sub[mode];
-  for (int s = beg; s < end; s += U) {
-    int4 r[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (s + u < end) r[u] = p.rec[base + s + u];
-    T xv[U][CPL], rv[U][CPL], ev[U][CPL];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (s + u >= end) continue;
-      const float *xr = p.x + int64_t(r[u].x) * p.ldx;
-      const float *rr = (r[u].y < p.rel_rows - 1) ? p.rel + int64_t(r[u].y) * p.d : p.loop_rel;
-      const int64_t slot = base + s + u;
-      const float *er = p.ee ? p.ee + (p.ee_slot_order ? slot - ee_sub_mode : int64_t(r[u].w)) * p.d : nullptr;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int ch = lane_in_group + c * gs;
-        if (ch < nchunk) {
-          xv[u][c] = V::load(xr + ch * VEC);
-          rv[u][c] = V::load(rr + ch * VEC);
-          if (er) ev[u][c] = V::load(er + ch * VEC);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (s + u < end) {
-        const float w = __int_as_float(r[u].z);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          const int ch = lane_in_group + c * gs;
-          if (ch < nchunk) {
-            T m = V::mul(xv[u][c], rv[u][c]);
-            if (p.ee) m = V::mul(m, ev[u][c]);
-            acc[c] = V::add(acc[c], V::muls(m, w));
-          }
-        }
-      }
-    }
-  }
+  walk_slots<VEC, CPL, U, ROLL>(p, rp[node], rp[node + 1], p.ee_sub[mode], col, lane_in_group, gs, acc);
   if (p.hubinfo) {  // a hub's own segment above is empty: its total was folded into the row of its first chunk
     const int2 hi = p.hubinfo[int64_t(mode) * p.n + node];
     if (hi.y > 0) {
 #pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int ch = lane_in_group + c * gs;
-        if (ch < nchunk) acc[c] = V::add(acc[c], V::load(p.partial + int64_t(hi.x - p.chunk0) * p.d + ch * VEC));
-      }
+      for (int c = 0; c < CPL; ++c) acc[c] = V::add(acc[c], V::load(p.partial + int64_t(hi.x - p.chunk0) * p.d + col[c]));
     }
   }
 #pragma unroll
@@ -215,12 +245,9 @@ __device__ __forceinline__ void hub_fold_rows(float *rows, int count, int64_t rs
     if (lane_in_group + c * gs < nchunk) V::store_agent(rows + col[c], tot[c]);
 }
 
-// Hub pre-pass: one lane group per chunk of a hub destination's slots; same arithmetic and slot order as above. A chunk is a chain
-// of dependent round trips for its group (there are few groups: ~4 waves per CU on the FB15k-237 shape), so the chain is kept short:
-// the group's lanes fetch 2 * GS records with two loads up front and hand them round by lane shuffles, and the rows of batch b + 1 are
-// in flight while batch b is added up (two register sets). The loop body is free of branches around loads (slot index clamped to the
-// chunk's last slot, column clamped to the row's last chunk, the relation / self-loop row chosen by offset; only the adds are
-// predicated), so the compiler counts the outstanding loads instead of draining them.
+// Hub pre-pass: one lane group per chunk of a hub destination's slots; same arithmetic and slot order (walk_slots). There are few
+// groups (~4 waves per CU on the FB15k-237 shape), each a chain of dependent round trips kept short by the walk's record windows and
+// its rolling prefetch.
 template <int VEC, int CPL, int U, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void agg_hub_kernel(AggArgs p, int gs_log2) {
   using V = Vec<VEC>;
@@ -231,64 +258,13 @@ __global__ __launch_bounds__(256, OCC) void agg_hub_kernel(AggArgs p, int gs_log
   if (chunk >= p.nchunks) return;
   const int nchunk = p.d / VEC;
   const int4 range = p.chunks[p.chunk0 + chunk];
-  const int end = range.y, last = end - 1;
   int col[CPL];                                   // this lane's columns (clamped: lanes past the row load its last chunk and store nothing)
 #pragma unroll
   for (int c = 0; c < CPL; ++c) col[c] = min(lane_in_group + c * gs, nchunk - 1) * VEC;
-  const int64_t loop_off = p.loop_rel - p.rel;    // the self-loop row as an offset from the relation table
-  const float *ee = p.ee ? p.ee : p.x;            // no per-edge table: a valid address, the value is not used
-  const bool has_ee = p.ee != nullptr;
   T acc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
-  for (int beg = range.x; beg < end; beg += 2 * gs) {        // (one pass unless the graph was built with chunks of more than 2 * GS slots)
-    const int stop = min(beg + 2 * gs, end);
-    const int nb = (stop - beg + U - 1) / U;
-    const int4 win0 = p.rec[min(beg + lane_in_group, last)], win1 = p.rec[min(beg + gs + lane_in_group, last)];
-    T xa[U][CPL], ra[U][CPL], ea[U][CPL], xb[U][CPL], rb[U][CPL], eb[U][CPL];
-    float wa[U], wb[U];
-    auto issue = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int s = min(beg + b * U + u, last);
-        const int idx = min(s - beg, 2 * gs - 1);
-        const bool hi = idx >= gs;
-        int4 r;
-        r.x = __shfl(hi ? win1.x : win0.x, idx, gs); r.y = __shfl(hi ? win1.y : win0.y, idx, gs);
-        r.z = __shfl(hi ? win1.z : win0.z, idx, gs); r.w = __shfl(hi ? win1.w : win0.w, idx, gs);
-        wt[u] = __int_as_float(r.z);
-        const float *xr = p.x + int64_t(r.x) * p.ldx;
-        const float *rr = p.rel + ((r.y < p.rel_rows - 1) ? int64_t(r.y) * p.d : loop_off);
-        const float *er = ee + (has_ee ? (p.ee_slot_order ? int64_t(s) - p.ee_sub_hub : int64_t(r.w)) * p.d : int64_t(0));
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          xv[u][c] = V::load(xr + col[c]);
-          rv[u][c] = V::load(rr + col[c]);
-          ev[u][c] = V::load(er + col[c]);
-        }
-      }
-    };
-    auto consume = [&](T (&xv)[U][CPL], T (&rv)[U][CPL], T (&ev)[U][CPL], float (&wt)[U], int b) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (beg + b * U + u < stop) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            T m = V::mul(xv[u][c], rv[u][c]);
-            if (has_ee) m = V::mul(m, ev[u][c]);
-            acc[c] = V::add(acc[c], V::muls(m, wt[u]));
-          }
-        }
-      }
-    };
-    issue(xa, ra, ea, wa, 0);
-    for (int b = 0; b < nb; b += 2) {
-      issue(xb, rb, eb, wb, b + 1);
-      consume(xa, ra, ea, wa, b);
-      issue(xa, ra, ea, wa, b + 2);
-      consume(xb, rb, eb, wb, b + 1);
-    }
-  }
+  walk_slots<VEC, CPL, U, true>(p, range.x, range.y, p.ee_sub_hub, col, lane_in_group, gs, acc);
 #pragma unroll
   for (int c = 0; c < CPL; ++c) {
     const int ch = lane_in_group + c * gs;
@@ -869,9 +845,10 @@ extern "C" int mgcn_aggregate_fwd(int64_t num_nodes, int64_t num_edges_half, int
     if (g.vec == 4) {
       switch (g.cpl) {
         case 1:
-          // slots in flight per lane group: short runs (WN18RR: 2.1 slots per destination and half) are covered by
-          // two, and the 58-register build runs eight waves per SIMD instead of five — measured 43 / 68 us against
-          // 46 / 78 us per WN18RR layer; long runs (FB15k-237: 18.7) keep four (83 / 139 us against 86 / 142)
+          // slots per batch: short runs (WN18RR: 2.1 slots per destination and half) are covered by two and the smaller
+          // build runs more waves per SIMD (44 / 72 us per WN18RR layer against 49 / 84 with four); long runs (FB15k-237:
+          // 18.7) take four (96 / 157 us with the hub pre-pass against 98 / 159). A rolling second batch (walk_slots<ROLL>)
+          // pays only in the hub pre-pass: on short runs it issues two batches past the run's end (56 / 96 us).
           if (num_edges_half < 4 * num_nodes) { MGCN_FWD_CASE(4, 1, 2); } else { MGCN_FWD_CASE(4, 1, 4); }
           break;
         case 2: MGCN_FWD_CASE(4, 2, 2); break;
