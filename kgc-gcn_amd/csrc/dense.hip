@@ -521,21 +521,40 @@ __global__ __launch_bounds__(SS_THREADS, 2) void score_split_kernel(TileArgs p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int fr = lane & 15, fq = lane >> 4;
   const int c0 = int(blockIdx.y) * BQ;
-  // the strip's queries -> LDS, split: item = (8-k group, query); consecutive threads take consecutive queries
-  for (int it = tid; it < nkb * 4 * BQ; it += SS_THREADS) {
-    const int q = it % BQ, kg = it / BQ, k0 = 8 * kg;
-    int col = c0 + q;
-    col = col < p.ncols ? col : p.ncols - 1;       // queries past the batch repeat the last one, never stored or counted
-    const float *src = p.b + int64_t(col) * p.ldb + k0;
-    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-    if (k0 < p.k) lo = *reinterpret_cast<const float4 *>(src);
-    if (k0 + 4 < p.k) hi = *reinterpret_cast<const float4 *>(src + 4);
-    u32x4s h, m, l;
-    split8_(lo, hi, h, m, l);
-    unsigned char *dst = ss + (kg * BQ + q) * 16;
-    *reinterpret_cast<u32x4s *>(dst) = h;
-    *reinterpret_cast<u32x4s *>(dst + piece) = m;
-    *reinterpret_cast<u32x4s *>(dst + 2 * piece) = l;
+  // the strip's queries -> LDS, split: item = (8-k group, query); consecutive threads take consecutive queries; four items' loads
+  // in flight per thread (indices clamped, stores predicated: no branch around a load)
+  {
+    const int items = nkb * 4 * BQ;
+    constexpr int SU = 4;
+    for (int it0 = tid; it0 < items; it0 += SU * SS_THREADS) {
+      float4 lo[SU], hi[SU];
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        int it = it0 + j * SS_THREADS;
+        it = it < items ? it : items - 1;
+        const int q = it % BQ, k0 = 8 * (it / BQ);
+        int col = c0 + q;
+        col = col < p.ncols ? col : p.ncols - 1;       // queries past the batch repeat the last one, never stored or counted
+        const float *src = p.b + int64_t(col) * p.ldb;
+        const int ka = k0 < p.k ? k0 : 0, kb2 = k0 + 4 < p.k ? k0 + 4 : 0;   // (K % 4 == 0; columns past K read column 0, zeroed below)
+        lo[j] = *reinterpret_cast<const float4 *>(src + ka);
+        hi[j] = *reinterpret_cast<const float4 *>(src + kb2);
+        if (k0 >= p.k) lo[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 + 4 >= p.k) hi[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < SU; ++j) {
+        const int it = it0 + j * SS_THREADS;
+        if (it < items) {
+          u32x4s h, m, l;
+          split8_(lo[j], hi[j], h, m, l);
+          unsigned char *dst = ss + it * 16;             // (= (kg * BQ + q) * 16)
+          *reinterpret_cast<u32x4s *>(dst) = h;
+          *reinterpret_cast<u32x4s *>(dst + piece) = m;
+          *reinterpret_cast<u32x4s *>(dst + 2 * piece) = l;
+        }
+      }
+    }
   }
   if (EPI == EPI_RANK) {
     for (int i = tid; i < BQ * 3; i += SS_THREADS) cnt[i] = 0;
@@ -599,8 +618,8 @@ __global__ __launch_bounds__(SS_THREADS, 2) void score_split_kernel(TileArgs p) 
 #pragma unroll
       for (int t = 0; t < NQT; ++t) acc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float4 alo[RT], ahi[RT], nlo[RT], nhi[RT];
-    aload(alo, ahi, 0);
+    float4 rlo[2][RT], rhi[2][RT];
+    aload(rlo[0], rhi[0], 0);
     uint32_t mw[NQT];
     float bv[RT][4];
     if (EPI == EPI_RANK) {
@@ -622,8 +641,7 @@ __global__ __launch_bounds__(SS_THREADS, 2) void score_split_kernel(TileArgs p) 
         }
       }
     }
-    for (int kb = 0; kb < nkb; ++kb) {
-      if (kb + 1 < nkb) aload(nlo, nhi, kb + 1);
+    auto kblock = [&](const float4 (&alo)[RT], const float4 (&ahi)[RT], int kb) __attribute__((always_inline)) {
       u32x4s ah[RT], am[RT], al[RT];
 #pragma unroll
       for (int h = 0; h < RT; ++h) split8_(alo[h], ahi[h], ah[h], am[h], al[h]);
@@ -646,10 +664,14 @@ __global__ __launch_bounds__(SS_THREADS, 2) void score_split_kernel(TileArgs p) 
           acc[h][t] = c;
         }
       }
+    };
+    for (int kb = 0; kb < nkb; ++kb) {
+      if (kb + 1 < nkb) aload(rlo[1], rhi[1], kb + 1);
+      kblock(rlo[0], rhi[0], kb);
 #pragma unroll
       for (int h = 0; h < RT; ++h) {
-        alo[h] = nlo[h];
-        ahi[h] = nhi[h];
+        rlo[0][h] = rlo[1][h];
+        rhi[0][h] = rhi[1][h];
       }
     }
     // lane holds entities (RT tu + h) * 16 + 4 fq + j (j = 0..3) of query column c0 + 16 t + fr
@@ -932,7 +954,11 @@ int launch_split(const TileArgs &p, hipStream_t stream, const char *name) {
     return mgcn::fail(MGCN_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", name, lds);
   const unsigned gy = unsigned((p.ncols + SS_BQ - 1) / SS_BQ);
   const int64_t tiles16 = (p.m + 15) / 16;
-  int64_t gx = 512 / gy;                                  // at most 512 blocks of 8 waves: two even rounds on 256 CUs
+  // Blocks: the kernel's ~190 VGPRs leave room for ONE block of 8 waves per CU, so blocks beyond 256 run as a second round that
+  // pays the block's fixed cost (its strip split into LDS, its first row loads, its counters) again. Up to 32 strips exactly 256
+  // blocks (128 queries 39 -> 33 us, 512: 82 -> 71, 2048: 246 -> 242: tools/bench_rank_block.py); beyond, 512 / strips per strip
+  // keeps the rounds even (6 268 queries: 754 us against 927 with 256 / strips = 2, which leaves 60 CUs idle).
+  int64_t gx = (gy <= 32 ? 256 : 512) / gy;
   const int64_t cap = ((tiles16 + 1) / 2 + 7) / 8;        // (a wave takes pairs of row tiles)
   gx = gx < cap ? gx : cap;
   if (EPI == EPI_TARGET || gx < 1) gx = 1;
