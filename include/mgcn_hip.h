@@ -229,6 +229,12 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * rel_out_dev (optional, [num_rel_rows - 1, dim_out]) = rel_dev @ rels_weight_dev [dim_in, dim_out] (model.py:107, the
  * relations the next layer / the scorer read) computed by the gather waves of the same launch after their last stage,
  * with the arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed.
+ * row_bounds_dev (optional; NULL / 0 = equal runs): num_row_bounds + 1 strictly increasing row offsets from node_begin, first 0,
+ * last node_end - node_begin: workgroup i of the elastic kernel takes destinations [b_i, b_i+1) — the caller's work-balanced runs
+ * (slots + a constant per row; one run per CU), computed once per graph on the host (GraphCSR.workgroup_bounds). Rows do not
+ * depend on the runs (fixed k order per row). With bounds given, a lockstep shape whose tiling would leave the chip short of two
+ * tiles per CU takes the elastic kernel (dim_out > 128). The bounds are read by the launch, not checked: offsets outside the
+ * range are the caller's error.
  * tune: 0 = automatic. For A/B runs of the layer_fused3.hip geometry only (never needed for correctness): bits 0-3 row
  * tiles per tile (3..5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS (1 = never), bits 10-11 = 3 forces
  * layer_fused3.hip on a shape of the other kernel (dim_out > 128 only), bits 12-13 input columns per slot walk (1 = 128,
@@ -242,7 +248,8 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
                          float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin, int64_t node_end,
                          int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, const int32_t *hubinfo_dev,
                          const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
-                         const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream);
+                         const float *rels_weight_dev, float *rel_out_dev, const int32_t *row_bounds_dev,
+                         int32_t num_row_bounds, int32_t tune, void *stream);
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
 

@@ -30,7 +30,7 @@ _SIGNATURES = {
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
-                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i32, _ptr]),
+                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
@@ -294,6 +294,16 @@ FUSED_TUNE = int(os.environ.get('MGCN_FUSED_TUNE', '0'), 0)
 FUSED_ENABLED = os.environ.get('MGCN_FUSED', '1') != '0'
 
 
+_CU_COUNT = {}
+
+
+def _cu_count(device):
+    key = str(device)
+    if key not in _CU_COUNT:
+        _CU_COUNT[key] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return _CU_COUNT[key]
+
+
 def fused_supported(d_in, d_out):
     """Shapes the one-launch layer kernel handles (else: aggregate_fwd + dense_bn_tanh_fwd)."""
     return FUSED_ENABLED and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0 and d_out <= 512
@@ -317,11 +327,13 @@ def pack_weights(w_cat, out=None):
 
 def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_packed, d_out, bias, bn_mean, bn_var,
                     bn_gamma, bn_beta, eps, out, node_range=None, ee_sub=(0, 0, 0), rels_weight=None, rel_out=None,
-                    tune=None):
+                    tune=None, balance=True):
     """(2)+(4) in one launch: out = tanh(BN_eval((aggregates @ W) / 3 + bias)), aggregates kept in LDS.
     `w_packed` = pack_weights(stacked [3D, O] weights). With `node_range` = (n0, n1) only those destinations are
     computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
-    graph.GraphCSR.edge_table_shard) with `ee_sub` its three slot offsets (in-half, out-half, hub region)."""
+    graph.GraphCSR.edge_table_shard) with `ee_sub` its three slot offsets (in-half, out-half, hub region).
+    `balance`: hand the launch the graph's work-balanced per-workgroup row runs (GraphCSR.workgroup_bounds, one run per
+    CU); results do not depend on it."""
     N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), int(d_out)
     n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
     if not 0 <= n0 <= n1 <= N:
@@ -358,6 +370,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
     if ee is not None and ee.numel() == 0:           # a range whose destinations have no slots: the kernel still wants
         ee = x.new_zeros((1, D))                     # a valid (never read) table pointer
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
+    bounds = csr.workgroup_bounds(n0, n1, _cu_count(x.device)) if balance and n1 > n0 else None
     rc = lib().mgcn_layer_fwd_fused(
         N, E, D, O, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
@@ -368,7 +381,8 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         _dev(out, torch.float32, 'out'), _ld(out), n0, n1, int(ee_sub[0]), int(ee_sub[1]), int(ee_sub[2]),
         hub_info, hub_chunks, hub_c0, hub_c1,
         _dev(hub_partial, torch.float32, 'partial', True), _dev(rels_weight, torch.float32, 'rels_weight', True),
-        _dev(rel_out, torch.float32, 'rel_out', True), FUSED_TUNE if tune is None else int(tune), _stream(x))
+        _dev(rel_out, torch.float32, 'rel_out', True), _dev(bounds, torch.int32, 'row_bounds', True),
+        bounds.numel() - 1 if bounds is not None else 0, FUSED_TUNE if tune is None else int(tune), _stream(x))
     if rc == 3:
         raise FusedUnsupported('mgcn_layer_fwd_fused: %s' % lib().mgcn_last_error().decode())
     _check(rc, 'mgcn_layer_fwd_fused')

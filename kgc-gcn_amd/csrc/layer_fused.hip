@@ -38,7 +38,8 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                     int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub,
                                     const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t chunk_begin,
                                     int64_t chunk_end, float *partial_dev, const float *rels_weight_dev,
-                                    float *rel_out_dev, int32_t tune, void *stream) {
+                                    float *rel_out_dev, const int32_t *row_bounds_dev, int32_t num_row_bounds,
+                                    int32_t tune, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
                "layer_fwd_fused: bad sizes");
   MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "layer_fwd_fused: bad node range");
@@ -70,7 +71,17 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   // tune bits 10-11 = 3: the elastic kernel on a lockstep shape (A/B runs; the two packings coincide for O > 128 only)
   const bool force3 = ((tune >> 10) & 3) == 3;
   MGCN_REQUIRE(!force3 || dim_out > 128, "layer_fwd_fused: tune %d: the elastic kernel reads another packing for O <= 128", tune);
-  if (lockstep_shape(dim_in, dim_out) && !force3)
+  MGCN_REQUIRE(num_row_bounds >= 0 && num_row_bounds <= 4096 && (num_row_bounds == 0 || row_bounds_dev),
+               "layer_fwd_fused: bad row bounds");
+  // Work-balanced runs are the elastic kernel's: a lockstep shape takes it too when the lockstep tiling would leave the
+  // chip short of two tiles per CU (FB15k-237: 228 tiles of 64 rows on 256 CUs, the heaviest tile 1.15x the mean) and
+  // the two packings coincide (O > 128).
+  int cus = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const bool few_tiles = (node_end - node_begin + 79) / 80 < 2 * int64_t(cus);
+  const bool balanced3 = num_row_bounds > 0 && few_tiles && dim_out > 128;
+  if (lockstep_shape(dim_in, dim_out) && !force3 && !balanced3)
     return mgcn::fused2_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
@@ -80,5 +91,6 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
                                num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
-                               want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, tune, stream);
+                               want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, row_bounds_dev,
+                               num_row_bounds, tune, stream);
 }

@@ -55,6 +55,7 @@ struct Args3 {
   int32_t npass, nkb_last, kbp, kbm, G;   // passes per mode, k-blocks of the last pass / of a full pass / per mode / per tile
   int32_t ncc;            // 16-byte chunk columns of a stage image (8 bf16 each)
   int32_t rows_per_wg, nimg;
+  const int32_t *bounds;   // [grid + 1] row offsets from node0 of the workgroups' runs (work-balanced), or null: equal runs
   float bn_eps;
 #ifdef MGCN_DIAG
   unsigned long long *diag;   // [grid][16 waves][4]: cycles in the kernel, cycles waiting for an image, waits, stages
@@ -130,8 +131,13 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int nimg = p.nimg;
-  const int row_lo = p.node0 + bid * p.rows_per_wg;                        // this workgroup's run of destinations
-  const int row_hi = row_lo + p.rows_per_wg < p.node1 ? row_lo + p.rows_per_wg : p.node1;
+  int row_lo = p.node0 + bid * p.rows_per_wg;                              // this workgroup's run of destinations
+  int row_hi = row_lo + p.rows_per_wg < p.node1 ? row_lo + p.rows_per_wg : p.node1;
+  if (p.bounds) {                                                          // ... or the caller's (work-balanced) run
+    row_lo = p.node0 + p.bounds[bid];
+    row_hi = p.node0 + p.bounds[bid + 1];
+    row_hi = row_hi < p.node1 ? row_hi : p.node1;
+  }
   const int myrows = row_hi > row_lo ? row_hi - row_lo : 0;
   const int my_tiles = (myrows + BM - 1) / BM;
   const int npass = p.npass;
@@ -816,7 +822,8 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
                   const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev, const float *bn_gamma_dev,
                   const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
                   int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
-                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream) {
+                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, const int32_t *row_bounds_dev,
+                  int32_t num_row_bounds, int32_t tune, void *stream) {
   const int t_nch = (tune >> 12) & 3;
   if (t_nch > 2) return mgcn::fail(MGCN_EINVAL, "layer_fwd_fused: bad tune %d", tune);
   const Shape3 s = shape3(dim_in, t_nch);
@@ -840,8 +847,12 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   const int64_t nrows = node_end - node_begin;
   int64_t rpw = ((nrows + cus - 1) / cus + 15) / 16 * 16;
   if (rpw < 16) rpw = 16;
-  const int grid = int(nrows > 0 ? (nrows + rpw - 1) / rpw : 1);
+  int grid = int(nrows > 0 ? (nrows + rpw - 1) / rpw : 1);
   p.rows_per_wg = int32_t(rpw);
+  if (row_bounds_dev && num_row_bounds > 0 && nrows > 0) {   // the caller's runs, one workgroup each (at most one per CU is the point)
+    p.bounds = row_bounds_dev;
+    grid = num_row_bounds;
+  }
   const int nt = pick_nt3(dim_out);
   const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;
   // Geometry: the tallest tile (weight fragments feed 6 * NRT MFMAs) that leaves room for three staging buffers, else two;

@@ -48,6 +48,8 @@ class GraphCSR(object):
             if v is not None:
                 setattr(self, k, v.to(device))
         self._inv_perm = None
+        self.__dict__.pop('_shard_cache', None)      # (holds device tensors of the old device: workgroup_bounds)
+        self.__dict__.pop('_hub_partials', None)
         return self
 
     @property
@@ -105,6 +107,28 @@ class GraphCSR(object):
             bounds.append(N)
             cache[key] = bounds
         return list(cache[key])
+
+    def workgroup_bounds(self, n0, n1, groups, row_weight=8):
+        """Row offsets (relative to n0) that cut destinations [n0, n1) into at most `groups` contiguous runs of about
+        equal WORK for the elastic fused launch (include/mgcn_hip.h (2b) row_bounds_dev): work(row) = its slots in both
+        halves + row_weight (the self-loop message, the row's share of the multiply, the output row; a hub's slots are
+        summed by the pre-pass, so a hub counts as a row without slots). int32 device tensor [g + 1], strictly
+        increasing from 0 to n1 - n0; cached per (range, groups)."""
+        n0, n1, groups = int(n0), int(n1), int(groups)
+        key = ('wg', n0, n1, groups, int(row_weight))
+        cache = self.__dict__.setdefault('_shard_cache', {})
+        if key not in cache:
+            n = n1 - n0
+            g = max(1, min(groups, n))
+            rp = self.rowptr[:, n0:n1 + 1].cpu().to(torch.int64)
+            prefix = (rp[0] - rp[0, 0]) + (rp[1] - rp[1, 0]) + row_weight * torch.arange(n + 1, dtype=torch.int64)
+            idx = torch.arange(1, g, dtype=torch.int64)
+            cuts = torch.searchsorted(prefix, (idx * int(prefix[-1])) // g)
+            cuts = torch.minimum(torch.maximum(cuts, idx), n - (g - idx))          # every run keeps at least one row
+            cuts = torch.cummax(cuts, 0).values if g > 1 else cuts
+            bounds = torch.cat([cuts.new_zeros(1), cuts, cuts.new_full((1,), n)]).to(torch.int32)
+            cache[key] = bounds.to(self.rowptr.device)
+        return cache[key]
 
     def shard_slot_counts(self, n0, n1):
         (i0, i1), (o0, o1), (h0, h1) = self._shard_bounds(n0, n1)

@@ -251,3 +251,40 @@ def test_hub_fold_inside_the_prepass_launch(pkg, oracle, D):
     nat.aggregate_fwd(csr, x, rel, csr.edge_table_shard(table, n0, n1), True, loop_edge, part, node_range=(n0, n1),
                       ee_sub=csr.shard_ee_sub(n0, n1), out_row0=n0)
     assert torch.equal(part, out[n0:n1])
+
+
+@pytest.mark.parametrize('zipf', [0.0, 1.2])
+def test_work_balanced_runs_do_not_change_rows(pkg, oracle, zipf):
+    """mgcn_layer_fwd_fused's row_bounds_dev (GraphCSR.workgroup_bounds: one work-balanced run of destinations per CU):
+    the elastic kernel's rows are bit-identical with and without them, for the whole graph and for a destination
+    range with its table shard, and match the oracle (model.py:82-109) like every other launch."""
+    N, R, E, D, O = 5000, 11, 60000, 100, 200
+    ei, ea, csr = _graph(pkg, oracle, N, R, E, seed=9, zipf=zipf)
+    conv = _layer(pkg, D, O, R, seed=4, bias=True)
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(N, D, generator=g) * 0.5).to(DEV)
+    rel = (torch.randn(2 * R, D, generator=g) * 0.5).to(DEV)
+    ee = (torch.randn(2 * E, D, generator=g) * 0.5).to(DEV)
+    table = ee.index_select(0, csr.perm)
+    nat = pkg._native
+    bn = conv.ent_bn
+    _, wpack = conv.derived_weights()
+
+    def launch(balance, tune, rng=None):
+        n0, n1 = rng or (0, N)
+        out = torch.empty((n1 - n0, O), device=DEV)
+        tab = table if rng is None else csr.edge_table_shard(table, n0, n1)
+        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), tab, True, conv.loop_edge.reshape(-1), wpack, O, conv.bias,
+                            bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out, node_range=rng,
+                            ee_sub=(0, 0, 0) if rng is None else csr.shard_ee_sub(n0, n1), tune=tune, balance=balance)
+        return out
+    bounds = csr.workgroup_bounds(0, N, 256).cpu().numpy()
+    assert bounds[0] == 0 and bounds[-1] == N and (np.diff(bounds) > 0).all() and len(bounds) == 257
+    plain = launch(False, 0xc00)                 # the elastic kernel, equal runs
+    assert torch.equal(launch(True, 0xc00), plain)
+    assert torch.equal(launch(True, 0), plain)   # 63 lockstep tiles < 2 x CUs: the balanced launch is the elastic kernel
+    part = launch(True, 0, (1234, 4321))
+    assert torch.equal(part, plain[1234:4321])
+    sd = {'conv1.' + k: v.detach().cpu() for k, v in conv.state_dict().items()}
+    want, _ = oracle.layer_forward(sd, 'conv1.', x.cpu(), ei, ea[0], ee.cpu(), rel.cpu(), training=False)
+    np.testing.assert_allclose(plain.cpu().numpy(), want.numpy(), rtol=0, atol=2e-4 if zipf else 5e-5)

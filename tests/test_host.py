@@ -474,7 +474,7 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         ('mgcn_aggregate_bwd', (4, 2, 0, 3, N, N, N, N, N, N, 0, N, N, N, 4, N, N, N, 8, N, N, N, N, 0, N), 'bad sizes'),
         ('mgcn_dense_bn_tanh_fwd', (4, 4, 4, N, 12, N, N, N, N, N, N, 1e-5, N, 4, N), 'null pointer'),
         ('mgcn_layer_fwd_fused', (4, 2, 4, 4, 3, N, N, N, 4, N, N, N, 1, N, N, N, N, N, N, N, 1e-5, N, 4, 2, 1, 0, 0, 0, N, N, 0,
-                                  0, N, N, N, 0, N), 'bad node range'),
+                                  0, N, N, N, N, 0, 0, N), 'bad node range'),
         ('mgcn_score_fwd', (4, 8, 4, N, 4, N, 4, N, N, 8, N), 'null pointer'),
         ('mgcn_score_rank', (4, 8, 0, 4, N, 4, N, 4, N, N, N, N, 0, N, 0, N, N), 'null pointer'),
         ('mgcn_filter_mask', (4, N, 0, N, N, N, 0, 8, N, 1, N), 'null pointer'),
@@ -592,3 +592,21 @@ def test_resumed_optimizer_state_follows_the_table_rows(pkg, tmp_path):
     want, got = model.state_dict(), resumed.state_dict()
     for k in want:
         assert torch.equal(want[k], got[k]), k
+
+
+def test_workgroup_bounds_balance_the_work(pkg):
+    """GraphCSR.workgroup_bounds (the elastic fused launch's per-workgroup runs): strictly increasing from 0 to the
+    range's length, at most `groups` runs, and no run carries much more than the mean work (slots + 8 per row)."""
+    from oracle import mgcn_oracle as oracle
+    N, R, E = 3000, 5, 40000
+    tri = oracle.synthetic_triples(N, R, E, seed=3, zipf=1.1)
+    ei, ea = oracle.build_edge_list(tri, R)
+    csr = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei), torch.from_numpy(ea)[0], torch.device('cpu'))
+    rp = csr.rowptr.to(torch.int64)
+    for n0, n1, groups in ((0, N, 256), (100, 2900, 64), (5, 25, 256), (7, 8, 4)):
+        b = csr.workgroup_bounds(n0, n1, groups).to(torch.int64)
+        n = n1 - n0
+        assert b[0] == 0 and b[-1] == n and bool((b[1:] > b[:-1]).all()) and b.numel() - 1 == min(groups, n)
+        work = (rp[0, n0 + b[1:]] - rp[0, n0 + b[:-1]]) + (rp[1, n0 + b[1:]] - rp[1, n0 + b[:-1]]) + 8 * (b[1:] - b[:-1])
+        rowmax = int(((rp[0, n0 + 1:n1 + 1] - rp[0, n0:n1]) + (rp[1, n0 + 1:n1 + 1] - rp[1, n0:n1])).max()) + 8
+        assert int(work.max()) <= float(work.sum()) / (b.numel() - 1) + rowmax      # mean + one row
