@@ -112,8 +112,8 @@ class GraphCSR(object):
         """Row offsets (relative to n0) that cut destinations [n0, n1) into at most `groups` contiguous runs of about
         equal WORK for the elastic fused launch (include/mgcn_hip.h (2b) row_bounds_dev): work(row) = its slots in both
         halves + row_weight (the self-loop message, the row's share of the multiply, the output row; a hub's slots are
-        summed by the pre-pass, so a hub counts as a row without slots). int32 device tensor [g + 1], strictly
-        increasing from 0 to n1 - n0; cached per (range, groups)."""
+        summed by the pre-pass, so a hub counts as a row without slots). No run is longer than ceil(rows per run / 80)
+        tiles of 80 rows. int32 device tensor [g + 1], strictly increasing from 0 to n1 - n0; cached per (range, groups)."""
         n0, n1, groups = int(n0), int(n1), int(groups)
         key = ('wg', n0, n1, groups, int(row_weight))
         cache = self.__dict__.setdefault('_shard_cache', {})
@@ -126,7 +126,15 @@ class GraphCSR(object):
             cuts = torch.searchsorted(prefix, (idx * int(prefix[-1])) // g)
             cuts = torch.minimum(torch.maximum(cuts, idx), n - (g - idx))          # every run keeps at least one row
             cuts = torch.cummax(cuts, 0).values if g > 1 else cuts
-            bounds = torch.cat([cuts.new_zeros(1), cuts, cuts.new_full((1,), n)]).to(torch.int32)
+            # no run longer than the whole tiles an equal split would take (80-row tiles: a run one row longer costs a
+            # whole extra tile — its own pass over the weights): forward and backward clamps, feasible since g * cap >= n
+            cap = (-(-n // g) + 79) // 80 * 80
+            b = [0] + cuts.tolist() + [n]
+            for i in range(1, g):
+                b[i] = min(max(b[i], b[i - 1] + 1), b[i - 1] + cap)
+            for i in range(g - 1, 0, -1):
+                b[i] = max(b[i], b[i + 1] - cap)
+            bounds = torch.tensor(b, dtype=torch.int32)
             cache[key] = bounds.to(self.rowptr.device)
         return cache[key]
 
