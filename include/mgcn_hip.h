@@ -240,6 +240,9 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * tiles per tile (3..5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS (1 = never), bits 10-11 = 3 forces
  * layer_fused3.hip on a shape of the other kernel (dim_out > 128 only), bits 12-13 input columns per slot walk (1 = 128,
  * 2 = 256). */
+/* The kernel a launch of (2b) over num_rows destinations takes: 2 = lockstep (layer_fused2.hip), 3 = elastic (layer_fused3.hip).
+ * Informational (profiles, benchmarks name the kernel they measured); tune bits 10-11 override it. */
+int mgcn_fused_kernel_generation(int32_t dim_in, int32_t dim_out, int64_t num_rows, int32_t with_row_bounds);
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                          const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'mgcn_filter_mask': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     'mgcn_score_bce_partials': (_i64, [_i32, _i64]),
     'mgcn_hub_partial_floats': (_i64, [_i64, _i32]),
+    'mgcn_fused_kernel_generation': (ctypes.c_int, [_i32, _i32, _i64, _i32]),
     'mgcn_score_bce_fwd': (ctypes.c_int, [_i32, _i64, _i32, _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr,
                                           _i64, _ptr, _ptr]),
     'mgcn_label_rows': (ctypes.c_int, [_i32, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr, _i64, _ptr]),
@@ -333,7 +334,7 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
     computed and `out` is [n1 - n0, O]; `ee` may then be this range's shard of the slot-ordered table (see
     graph.GraphCSR.edge_table_shard) with `ee_sub` its three slot offsets (in-half, out-half, hub region).
     `balance`: hand the launch the graph's work-balanced per-workgroup row runs (GraphCSR.workgroup_bounds, one run per
-    CU); results do not depend on it."""
+    CU, None when equal runs are balanced already); results do not depend on it."""
     N, E, D, O = csr.num_nodes, csr.num_edges_half, x.size(1), int(d_out)
     n0, n1 = (0, N) if node_range is None else (int(node_range[0]), int(node_range[1]))
     if not 0 <= n0 <= n1 <= N:

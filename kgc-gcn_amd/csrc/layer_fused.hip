@@ -28,6 +28,18 @@ extern "C" int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w
   return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
 }
 
+// Which kernel a launch takes (2 = lockstep, layer_fused2.hip; 3 = elastic, layer_fused3.hip). Work-balanced runs are the elastic
+// kernel's: a lockstep shape takes it too when the lockstep tiling would leave the chip short of two tiles per CU (FB15k-237:
+// 228 tiles of 64 rows on 256 CUs, the heaviest tile 1.15x the mean) and the two packings coincide (O > 128).
+extern "C" int mgcn_fused_kernel_generation(int32_t dim_in, int32_t dim_out, int64_t num_rows, int32_t with_row_bounds) {
+  if (!lockstep_shape(dim_in, dim_out)) return 3;
+  int cus = 256, dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const bool few_tiles = (num_rows + 79) / 80 < 2 * int64_t(cus);
+  return (with_row_bounds && few_tiles && dim_out > 128) ? 3 : 2;
+}
+
 extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                                     int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
                                     const float *x_dev, int64_t ldx, const float *rel_dev, const float *loop_rel_dev,
@@ -73,15 +85,7 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   MGCN_REQUIRE(!force3 || dim_out > 128, "layer_fwd_fused: tune %d: the elastic kernel reads another packing for O <= 128", tune);
   MGCN_REQUIRE(num_row_bounds >= 0 && num_row_bounds <= 4096 && (num_row_bounds == 0 || row_bounds_dev),
                "layer_fwd_fused: bad row bounds");
-  // Work-balanced runs are the elastic kernel's: a lockstep shape takes it too when the lockstep tiling would leave the
-  // chip short of two tiles per CU (FB15k-237: 228 tiles of 64 rows on 256 CUs, the heaviest tile 1.15x the mean) and
-  // the two packings coincide (O > 128).
-  int cus = 256, dev = 0;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const bool few_tiles = (node_end - node_begin + 79) / 80 < 2 * int64_t(cus);
-  const bool balanced3 = num_row_bounds > 0 && few_tiles && dim_out > 128;
-  if (lockstep_shape(dim_in, dim_out) && !force3 && !balanced3)
+  if (!force3 && mgcn_fused_kernel_generation(dim_in, dim_out, node_end - node_begin, num_row_bounds > 0) == 2)
     return mgcn::fused2_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,

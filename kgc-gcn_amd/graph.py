@@ -108,20 +108,29 @@ class GraphCSR(object):
             cache[key] = bounds
         return list(cache[key])
 
-    def workgroup_bounds(self, n0, n1, groups, row_weight=8):
+    def workgroup_bounds(self, n0, n1, groups, row_weight=8, min_gain=1.08):
         """Row offsets (relative to n0) that cut destinations [n0, n1) into at most `groups` contiguous runs of about
         equal WORK for the elastic fused launch (include/mgcn_hip.h (2b) row_bounds_dev): work(row) = its slots in both
         halves + row_weight (the self-loop message, the row's share of the multiply, the output row; a hub's slots are
         summed by the pre-pass, so a hub counts as a row without slots). No run is longer than ceil(rows per run / 80)
-        tiles of 80 rows. int32 device tensor [g + 1], strictly increasing from 0 to n1 - n0; cached per (range, groups)."""
+        tiles of 80 rows. int32 device tensor [g + 1], strictly increasing from 0 to n1 - n0, or None when the heaviest of the
+        EQUAL runs carries less than `min_gain` times the mean work (nothing to gain); cached per (range, groups)."""
         n0, n1, groups = int(n0), int(n1), int(groups)
-        key = ('wg', n0, n1, groups, int(row_weight))
+        key = ('wg', n0, n1, groups, int(row_weight), float(min_gain))
         cache = self.__dict__.setdefault('_shard_cache', {})
         if key not in cache:
             n = n1 - n0
             g = max(1, min(groups, n))
             rp = self.rowptr[:, n0:n1 + 1].cpu().to(torch.int64)
             prefix = (rp[0] - rp[0, 0]) + (rp[1] - rp[1, 0]) + row_weight * torch.arange(n + 1, dtype=torch.int64)
+            # equal runs (the kernel's own split: ceil(n / groups) rows rounded up to 16) are kept when their heaviest run is
+            # within `min_gain` of the mean: balanced cuts then only add ragged last tiles (configs[4] slice: +2 %)
+            rpw = (-(-n // groups) + 15) // 16 * 16
+            eq = torch.arange(0, n + rpw, rpw, dtype=torch.int64).clamp(max=n)
+            eq_work = prefix[eq[1:]] - prefix[eq[:-1]]
+            if float(eq_work.max()) <= min_gain * float(prefix[-1]) / groups:
+                cache[key] = None
+                return None
             idx = torch.arange(1, g, dtype=torch.int64)
             cuts = torch.searchsorted(prefix, (idx * int(prefix[-1])) // g)
             cuts = torch.minimum(torch.maximum(cuts, idx), n - (g - idx))          # every run keeps at least one row

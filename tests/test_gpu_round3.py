@@ -278,7 +278,7 @@ def test_work_balanced_runs_do_not_change_rows(pkg, oracle, zipf):
                             bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out, node_range=rng,
                             ee_sub=(0, 0, 0) if rng is None else csr.shard_ee_sub(n0, n1), tune=tune, balance=balance)
         return out
-    bounds = csr.workgroup_bounds(0, N, 256).cpu().numpy()
+    bounds = csr.workgroup_bounds(0, N, 256, min_gain=0.0).cpu().numpy()
     assert bounds[0] == 0 and bounds[-1] == N and (np.diff(bounds) > 0).all() and len(bounds) == 257
     plain = launch(False, 0xc00)                 # the elastic kernel, equal runs
     assert torch.equal(launch(True, 0xc00), plain)

@@ -604,9 +604,14 @@ def test_workgroup_bounds_balance_the_work(pkg):
     csr = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei), torch.from_numpy(ea)[0], torch.device('cpu'))
     rp = csr.rowptr.to(torch.int64)
     for n0, n1, groups in ((0, N, 256), (100, 2900, 64), (5, 25, 256), (7, 8, 4)):
-        b = csr.workgroup_bounds(n0, n1, groups).to(torch.int64)
+        b = csr.workgroup_bounds(n0, n1, groups, min_gain=0.0).to(torch.int64)
         n = n1 - n0
         assert b[0] == 0 and b[-1] == n and bool((b[1:] > b[:-1]).all()) and b.numel() - 1 == min(groups, n)
         work = (rp[0, n0 + b[1:]] - rp[0, n0 + b[:-1]]) + (rp[1, n0 + b[1:]] - rp[1, n0 + b[:-1]]) + 8 * (b[1:] - b[:-1])
         rowmax = int(((rp[0, n0 + 1:n1 + 1] - rp[0, n0:n1]) + (rp[1, n0 + 1:n1 + 1] - rp[1, n0:n1])).max()) + 8
         assert int(work.max()) <= float(work.sum()) / (b.numel() - 1) + rowmax      # mean + one row
+    assert csr.workgroup_bounds(0, N, 128) is not None                              # 32-row equal runs fill 94 of 128 groups
+    uni = oracle.synthetic_triples(N, R, E, seed=4, zipf=0.0)
+    ei2, ea2 = oracle.build_edge_list(uni, R)
+    csr2 = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei2), torch.from_numpy(ea2)[0], torch.device('cpu'))
+    assert csr2.workgroup_bounds(0, N, 4) is None                                   # uniform tails, long runs: nothing to gain

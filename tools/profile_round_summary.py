@@ -67,8 +67,8 @@ def main():
            'note': 'fabric-side bytes per launch (Infinity-Cache hits are counted, not excluded)',
            'source_fingerprint': bench.source_fingerprint()}
     for shape, suffix in (('wn18rr', ''), ('fb15k237', '_fb')):
-        f = counter_per_dispatch(os.path.join(out, 'pmc_fetch' + suffix), 'layer_fused2_kernel')
-        w = counter_per_dispatch(os.path.join(out, 'pmc_write' + suffix), 'layer_fused2_kernel')
+        f = counter_per_dispatch(os.path.join(out, 'pmc_fetch' + suffix), 'layer_fused')
+        w = counter_per_dispatch(os.path.join(out, 'pmc_write' + suffix), 'layer_fused')
         n = min(len(f), len(w)) // 2 * 2
         f, w = f[-n:], w[-n:]                                      # launches alternate layer 1, layer 2
         res[shape] = {}
