@@ -171,9 +171,7 @@ def _hub_args(csr, d, device, n0, n1):
     key = (int(d), c0, c1, str(device))
     hit = cache.get(key)
     stream = torch.cuda.current_stream(device)
-    if hit is None:
-        if len(cache) >= 16:
-            cache.clear()
+    if hit is None:            # (never evicted: a captured launch keeps the buffer's address; one entry per width and range)
         hit = cache[key] = [torch.zeros(int(lib().mgcn_hub_partial_floats(c1 - c0, int(d))), dtype=torch.float32, device=device),
                             stream]
     elif hit[1] != stream and not torch.cuda.is_current_stream_capturing():
