@@ -251,6 +251,18 @@ def test_hub_fold_inside_the_prepass_launch(pkg, oracle, D):
     nat.aggregate_fwd(csr, x, rel, csr.edge_table_shard(table, n0, n1), True, loop_edge, part, node_range=(n0, n1),
                       ee_sub=csr.shard_ee_sub(n0, n1), out_row0=n0)
     assert torch.equal(part, out[n0:n1])
+    # the same buffer (chunk-sum rows + counters) under OTHER inputs, as the next layer of equal width uses it: nothing of
+    # the previous launch may survive in it (a stale chunk sum read by a fold would be off by far more than the bound)
+    x2 = (-2.0 * x + 0.25).contiguous()
+    out2 = torch.empty_like(out)
+    nat.aggregate_fwd(csr, x2, rel, table, True, loop_edge, out2)
+    msg2 = x2.cpu().double().numpy()[src] * rel.cpu().double().numpy()[typ] * table.cpu().double().numpy() * norm[:, None]
+    got2 = out2.cpu().double().numpy()
+    for h in range(2):
+        want2, mag2 = np.zeros((N, D)), np.zeros((N, D))
+        np.add.at(want2, dst[half == h], msg2[half == h])
+        np.add.at(mag2, dst[half == h], np.abs(msg2[half == h]))
+        assert (np.abs(got2[:, h * D:(h + 1) * D] - want2) <= 256 * 2.0 ** -24 * mag2 + 1e-30).all(), h
 
 
 @pytest.mark.parametrize('zipf', [0.0, 1.2])
