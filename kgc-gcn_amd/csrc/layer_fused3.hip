@@ -191,7 +191,11 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     int s_img = 0;
     uint32_t s_round = 0;
     auto acquire = [&]() __attribute__((always_inline)) {
-      if (s_round > 0) wait_ge(cnt + 4 + s_img, 8u * s_round);   // all 8 MFMA waves have converted the buffer's last tile
+      if (s_round > 0) {   // all 8 MFMA waves have converted the buffer's last tile (waiting for them at THEIR priority: -1 % on the configs[4] slice)
+        __builtin_amdgcn_s_setprio(0);
+        wait_ge(cnt + 4 + s_img, 8u * s_round);
+        __builtin_amdgcn_s_setprio(3);
+      }
       return stg0 + s_img * sbuf;
     };
     auto publish = [&]() __attribute__((always_inline)) {
