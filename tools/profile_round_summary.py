@@ -33,18 +33,20 @@ def main():
     out = sys.argv[1]
     rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
     prof = os.path.join(ROOT, 'profiles')
-    for tag, name in (('trace_l2', 'wn18rr_2layer'), ('trace_l1', 'wn18rr_1layer'), ('trace_fb', 'fb15k237'), ('trace_eval', 'eval'),
+    traffic_only = '--traffic-only' in sys.argv     # (the PMC passes run first, so that the traced bench lines can quote the file)
+    for tag, name in () if traffic_only else (('trace_l2', 'wn18rr_2layer'), ('trace_l1', 'wn18rr_1layer'), ('trace_fb', 'fb15k237'), ('trace_eval', 'eval'),
                       ('trace_scale', 'scale_shard')):
         shutil.copy(one(os.path.join(out, tag, '**', '*kernel_stats.csv')), os.path.join(prof, '%s_kernel_stats_%s.csv' % (rnd, name)))
-    for tag, name in (('bench_l2', 'wn18rr_2layer'), ('bench_l1', 'wn18rr_1layer'), ('bench_fb', 'fb15k237'), ('bench_eval', 'eval')):
+    for tag, name in () if traffic_only else (('bench_l2', 'wn18rr_2layer'), ('bench_l1', 'wn18rr_1layer'), ('bench_fb', 'fb15k237'), ('bench_eval', 'eval')):
         line = open(os.path.join(out, tag + '.json')).read().strip().splitlines()[-1]
         json.dump(json.loads(line), open(os.path.join(prof, '%s_bench_under_rocprof_%s.json' % (rnd, name)), 'w'), indent=1)
-    shard = {}
-    for tag in ('scale_512', 'scale_200'):
-        shard[tag] = json.loads(open(os.path.join(out, tag + '.json')).read().strip().splitlines()[-1])
-    shard['note'] = 'tools/bench_scale_shard.py: rank 0 of 8 of a 2M-entity / 20M-triple / dim-512 graph, the rank holding only its ' \
-                    '10.2 GB shard of the 81.9 GB table; scale_512 ran under rocprofv3 --kernel-trace (%s_kernel_stats_scale_shard.csv)' % rnd
-    json.dump(shard, open(os.path.join(prof, '%s_scale_shard.json' % rnd), 'w'), indent=1)
+    if not traffic_only:
+        shard = {}
+        for tag in ('scale_512', 'scale_200'):
+            shard[tag] = json.loads(open(os.path.join(out, tag + '.json')).read().strip().splitlines()[-1])
+        shard['note'] = 'tools/bench_scale_shard.py: rank 0 of 8 of a 2M-entity / 20M-triple / dim-512 graph, the rank holding only its ' \
+                        '10.2 GB shard of the 81.9 GB table; scale_512 ran under rocprofv3 --kernel-trace (%s_kernel_stats_scale_shard.csv)' % rnd
+        json.dump(shard, open(os.path.join(prof, '%s_scale_shard.json' % rnd), 'w'), indent=1)
     # calibration: tools/pmc_calibrate.py's 512 MiB streaming copy = the kernel with the largest WRITE_SIZE (exactly
     # 524 288 KiB); FETCH_SIZE of the same kernel gives the read scale (gfx950 counts half of a wide streaming read)
     def by_name(d):
