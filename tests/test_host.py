@@ -615,3 +615,14 @@ def test_workgroup_bounds_balance_the_work(pkg):
     ei2, ea2 = oracle.build_edge_list(uni, R)
     csr2 = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei2), torch.from_numpy(ea2)[0], torch.device('cpu'))
     assert csr2.workgroup_bounds(0, N, 4) is None                                   # uniform tails, long runs: nothing to gain
+
+
+def test_fused_kernel_generation_rule(pkg):
+    """mgcn_fused_kernel_generation (no device work): wide shapes take the elastic kernel; a lockstep shape takes it too
+    when the caller brings work-balanced runs, its lockstep tiling has fewer than two tiles per CU and O > 128
+    (FB15k-237: 182 tiles of 80 rows), and stays on the lockstep kernel otherwise (WN18RR: 512 tiles)."""
+    gen = pkg._native.lib().mgcn_fused_kernel_generation
+    assert gen(100, 200, 40943, 1) == 2 and gen(200, 200, 40943, 0) == 2
+    assert gen(100, 200, 14541, 1) == 3 and gen(100, 200, 14541, 0) == 2
+    assert gen(100, 64, 14541, 1) == 2                      # O <= 128: the two kernels read different packings
+    assert gen(512, 512, 250000, 0) == 3 and gen(512, 200, 250000, 1) == 3 and gen(200, 256, 40943, 0) == 3
