@@ -622,7 +622,7 @@ def kernel_breakdown(pkg, model, graph, K, shape, shape_name, n_layers, D, O):
         # north_star's roof for this path: HBM (SURVEY §8d algorithmic bytes / launch time / 8 TB/s). The dense step rides
         # in the same launch: its algorithmic flops against the exact-f32 MFMA peak (what round 1 paid) and the flops
         # actually issued (six bf16 products) against the bf16 peak are reported beside it, for BOTH layers.
-        gen = nat.lib().mgcn_fused_kernel_generation(dims[int(dom[-1]) - 1], O, N, 1)
+        gen = nat.tune_generation() or nat.lib().mgcn_fused_kernel_generation(dims[int(dom[-1]) - 1], O, N, 1)
         roof = {'kernel': 'layer_fused%d_kernel (%s)' % (gen, dom), 'bound': 'hbm', 'achieved': k['GBps'], 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': k['hbm_frac'], 'traffic': None,
                 'per_layer': {n: {'us': v['us'], 'hbm_frac': v['hbm_frac'], 'mfma_f32_frac': v['mfma_f32_frac'],

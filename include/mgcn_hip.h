@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MGCN_ABI_VERSION 3
+#define MGCN_ABI_VERSION 4
 
 enum {
   MGCN_OK = 0,
@@ -196,17 +196,24 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
 
 /* (2)+(4) in ONE launch (eval mode): out = tanh(BN_eval((A_in W_in + A_out W_out + A_loop W_loop)/3 + bias)); the
  * aggregates of (2) are built tile by tile in LDS and multiplied there, they never reach HBM. One 1024-thread workgroup
- * per CU: eight waves gather (32-lane groups, 16 bytes per lane, a group sums its destinations' slots in slot order:
- * the sums of (2)), eight waves multiply with v_mfma_f32_16x16x32_bf16 and run the epilogue on the accumulators. Two
- * kernels sit behind this entry point, chosen by shape alone:
- *   dim_in <= 256 and dim_out <= 208  csrc/layer_fused2.hip: tiles of 80 (or 64) destinations, stages of 128 input
- *       columns, two LDS images, one workgroup barrier per stage;
- *   otherwise (dim_in <= 1024, dim_out <= 512)  csrc/layer_fused3.hip: one contiguous run of rows per workgroup in
- *       tiles of 48-80, stages of 128 or 256 columns, a ring of f32 staging buffers coupled by LDS counters, 13 or 32
- *       column tiles.
+ * per CU owns one contiguous run of destinations; 32-lane groups (16 bytes per lane) sum their destinations' slots in
+ * slot order — the sums of (2) —, split each finished row exactly into three bf16 pieces in LDS, and
+ * v_mfma_f32_16x16x32_bf16 multiplies them; the epilogue runs on the accumulators. Kernels behind this entry point
+ * (mgcn_fused_kernel_generation tells which one a launch takes):
+ *   generation 2, dim_in <= 256 and dim_out <= 208  csrc/layer_fused2.hip: eight waves gather, eight multiply; tiles of 80
+ *       (or 64) destinations, stages of 128 input columns per mode, two LDS images, one workgroup barrier per stage;
+ *   generation 3, otherwise (dim_in <= 1024, dim_out <= 512), and generation 2's shapes when the caller brings row bounds
+ *       for a launch short of two tiles per CU  csrc/layer_fused3.hip: one contiguous run of rows per workgroup in tiles of
+ *       48-80, stages of 128 or 256 columns, a ring of f32 staging buffers coupled by LDS counters, 13 or 32 column tiles.
+ *       Generations 2 and 3 run the same arithmetic (k order, products, and for dim_out > 128 the weight packing): rows
+ *       are bit-identical between them;
+ *   generation 4, dim_in <= 256 and dim_out <= 208, ONLY through `tune`  csrc/layer_fused4.hip (round 4's experiment: all
+ *       sixteen waves gather a stage of up to 320 columns of the concatenated K axis, then all sixteen multiply it; own
+ *       packing, own k order: rows differ from generations 2 / 3 in the last bits; not faster, see LAB_NOTES.md).
  * Arguments as in (2) and (4), except that the weights are passed in MFMA fragment order: wp_dev = mgcn_pack_weights() of
  * the stacked [3*dim_in, dim_out] matrix (mgcn_packed_weights_bytes bytes, 16-byte aligned; re-pack whenever a weight
- * changes). Returns MGCN_EUNSUPPORTED (and does nothing) unless all operands are 16-byte aligned, ee_dev is given in
+ * changes; the *_gen forms pack for a generation forced through `tune`; 0 = the shape's own, which generations 2 and 3 share for
+ * dim_out > 128). Returns MGCN_EUNSUPPORTED (and does nothing) unless all operands are 16-byte aligned, ee_dev is given in
  * slot order, dim_in % 4 == 0, dim_in <= 1024, dim_out % 4 == 0 and dim_out <= 512 — callers then use (2) followed by (4).
  * NUMERIC CONTRACT. The dense step is not the exact-f32 MFMA of (4): every aggregate a and weight w is split EXACTLY
  * into three bf16 pieces (hi = bf16(v) rounded to nearest, mid = bf16(v - hi), lo = v - hi - mid; hi + mid + lo == v bit
@@ -214,8 +221,8 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * are below 2^-26 |a||w| per product. For finite inputs |out - exact| <= 4 u B + 2e-7 with u = 2^-24 and
  * B = sum_k |a_k||w_k| * |gamma| / (3 sqrt(var + eps)) (tests/test_gpu_round3.py holds both this launch and (2)+(4) to
  * it on rows with 2^40 of dynamic range; on the benchmark's data both are within 5e-7 of float64). Results are
- * bit-identical across launches of this entry point (whole graph, any destination range, any table shard, either
- * generation's geometry for the same shape) but differ from (2)+(4) in the last bits (<= 2e-6 on a tanh output for
+ * bit-identical across launches of this entry point with `tune` bits 10-11 = 0 (whole graph, any destination range, any
+ * table shard, any row bounds, either of generations 2 / 3, any tile geometry) but differ from (2)+(4) in the last bits (<= 2e-6 on a tanh output for
  * dim_in <= 256). A non-finite input (inf / NaN) in a gathered row makes that destination's output row NaN, where
  * (2)+(4) may return +-1; other rows are unaffected.
  * Destination partition: only destinations [node_begin, node_end) are computed; out_dev holds THOSE rows
@@ -227,21 +234,25 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * Hubs as in (2): hubinfo_dev / chunks_dev / [chunk_begin, chunk_end) / partial_dev [mgcn_hub_partial_floats(chunk_end -
  * chunk_begin, dim_in)] with its counters zero (one pre-pass launch before the layer's launch).
  * rel_out_dev (optional, [num_rel_rows - 1, dim_out]) = rel_dev @ rels_weight_dev [dim_in, dim_out] (model.py:107, the
- * relations the next layer / the scorer read) computed by the gather waves of the same launch after their last stage,
+ * relations the next layer / the scorer read) computed by the same launch after its last gather stage,
  * with the arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed.
  * row_bounds_dev (optional; NULL / 0 = equal runs): num_row_bounds + 1 strictly increasing row offsets from node_begin, first 0,
- * last node_end - node_begin: workgroup i of the elastic kernel takes destinations [b_i, b_i+1) — the caller's work-balanced runs
+ * last node_end - node_begin: workgroup i takes destinations [b_i, b_i+1) — the caller's work-balanced runs
  * (slots + a constant per row; one run per CU; no run longer than ceil(rows / runs / 80) * 80 rows, which is what the tile
  * height is chosen for), computed once per graph on the host (GraphCSR.workgroup_bounds). Rows do not
- * depend on the runs (fixed k order per row). With bounds given, a lockstep shape whose tiling would leave the chip short of two
- * tiles per CU takes the elastic kernel (dim_out > 128). The bounds are read by the launch, not checked: offsets outside the
- * range are the caller's error.
- * tune: 0 = automatic. For A/B runs of the layer_fused3.hip geometry only (never needed for correctness): bits 0-3 row
- * tiles per tile (3..5), bits 4-7 staging buffers (1..4), bits 8-9 relation table in LDS (1 = never), bits 10-11 = 3 forces
- * layer_fused3.hip on a shape of the other kernel (dim_out > 128 only), bits 12-13 input columns per slot walk (1 = 128,
- * 2 = 256). */
-/* The kernel a launch of (2b) over num_rows destinations takes: 2 = lockstep (layer_fused2.hip), 3 = elastic (layer_fused3.hip).
- * Informational (profiles, benchmarks name the kernel they measured); tune bits 10-11 override it. */
+ * depend on the runs (fixed k order per row). With bounds given, a generation-2 shape whose tiling would leave the chip short of
+ * two tiles per CU takes generation 3 (dim_out > 128); generation 2 itself ignores them. The bounds are read by the launch, not
+ * checked: offsets outside the range are the caller's error.
+ * tune: 0 = automatic. For A/B runs only (never needed for correctness): bits 0-3 row tiles per tile (3..5); bits 4-7
+ * generation 3: staging buffers (1..4), generation 4: slots per gather batch (2 / 4 / 8); bits 8-9 relation table in LDS
+ * (1 = never); bits 10-11 force a generation (1 = generation 4, 2, 3; wp_dev must then come from mgcn_pack_weights_gen for
+ * it); bits 12-13 generation 3: input columns per slot walk (1 = 128, 2 = 256).
+ * status_dev (optional, one zero-initialised uint32 in device memory): generation 3 couples its roles through LDS counters
+ * with BOUNDED spins; a spin that runs out (a wave parked for ~0.1 s by a debugger, a preemption, or a protocol error)
+ * lets its wave go on, the rows of that tile are then garbage, and bit 0 of *status_dev is set: callers check the word at
+ * their next synchronisation point (kgc-gcn_amd/_native.py check_fused_status). Generations 2 and 4 have no spins. */
+/* The kernel a launch of (2b) over num_rows destinations takes with `tune` bits 10-11 = 0: 2 (layer_fused2.hip) or 3
+ * (layer_fused3.hip). Informational (profiles, benchmarks name the kernel they measured). */
 int mgcn_fused_kernel_generation(int32_t dim_in, int32_t dim_out, int64_t num_rows, int32_t with_row_bounds);
 int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_in, int32_t dim_out,
                          int32_t num_rel_rows, const int32_t *rowptr_dev, const mgcn_edge_rec *rec_dev,
@@ -253,9 +264,12 @@ int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, int32_t dim_
                          int64_t ee_sub_in, int64_t ee_sub_out, int64_t ee_sub_hub, const int32_t *hubinfo_dev,
                          const int32_t *chunks_dev, int64_t chunk_begin, int64_t chunk_end, float *partial_dev,
                          const float *rels_weight_dev, float *rel_out_dev, const int32_t *row_bounds_dev,
-                         int32_t num_row_bounds, int32_t tune, void *stream);
+                         int32_t num_row_bounds, int32_t tune, uint32_t *status_dev, void *stream);
 int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes, void *stream);
 size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out);
+int mgcn_pack_weights_gen(int32_t generation, int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev,
+                          size_t wp_bytes, void *stream);
+size_t mgcn_packed_weights_bytes_gen(int32_t generation, int32_t dim_in, int32_t dim_out);
 
 /* ---------------------------------------------------------------------------------------------
  * (4t) The layer's epilogue in TRAINING mode and its backward (model.py:103-106 under .train(), driven by main.py:61-66):

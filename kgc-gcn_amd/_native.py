@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('MGCN_LIB') or os.path.join(_HERE, 'csrc', 'libmgcn_hip.so')   # MGCN_LIB: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -30,9 +30,12 @@ _SIGNATURES = {
     'mgcn_dense_bn_tanh_fwd': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64] + [_ptr] * 6 + [_f32, _ptr, _i64, _ptr]),
     'mgcn_layer_fwd_fused': (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i32,
                                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _i64, _i64,
-                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+                                            _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr,
+                                            _ptr]),
     'mgcn_pack_weights': (ctypes.c_int, [_i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
     'mgcn_packed_weights_bytes': (ctypes.c_size_t, [_i32, _i32]),
+    'mgcn_pack_weights_gen': (ctypes.c_int, [_i32, _i32, _i32, _ptr, _ptr, ctypes.c_size_t, _ptr]),
+    'mgcn_packed_weights_bytes_gen': (ctypes.c_size_t, [_i32, _i32, _i32]),
     'mgcn_matmul_f32': (ctypes.c_int, [_i64, _i32, _i32, _ptr, _i64, _ptr, _i64, _ptr, _i64, _ptr]),
     'mgcn_bn_tanh_train_workspace': (ctypes.c_size_t, [_i64, _i32]),
     'mgcn_bn_tanh_train_fwd': (ctypes.c_int, [_i64, _i32, _ptr, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _ptr,
@@ -180,6 +183,14 @@ def _hub_args(csr, d, device, n0, n1):
     return _dev(csr.hubinfo, torch.int32, 'hubinfo'), _dev(csr.chunks, torch.int32, 'chunks'), c0, c1, hit[0]
 
 
+def _hub_failed(csr, d, device, n0, n1):
+    """A launch that was handed the (width, chunk range) hub buffer returned an error: its fold may have stopped between two
+    arrivals and left counters non-zero, which would silently switch the NEXT launch's fold off. Forget the buffer: the next
+    launch gets a fresh zeroed one (a captured graph that holds the old address is invalid after a failed launch anyway)."""
+    c0, c1 = csr.chunk_range(n0, n1)
+    csr.__dict__.get('_hub_partials', {}).pop((int(d), c0, c1, str(device)), None)
+
+
 def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=None, node_range=None, ee_sub=(0, 0, 0),
                   out_row0=0):
     """(2) out[:, 0:D | D:2D | 2D:3D) = in / out / self-loop aggregates. `csr` is a graph.GraphCSR.
@@ -221,12 +232,15 @@ def aggregate_fwd(csr, x, rel, ee, ee_in_slot_order, loop_edge, out, loop_rel=No
         if ee.numel() == 0:
             ee = x.new_zeros((1, D))
     hub_info, hub_chunks, hub_c0, hub_c1, hub_partial = _hub_args(csr, D, x.device, n0, n1)
-    _check(lib().mgcn_aggregate_fwd(
+    rc = lib().mgcn_aggregate_fwd(
         N, E, D, csr.num_rel_rows, _dev(csr.rowptr, torch.int32, 'rowptr'), _dev(csr.rec, torch.int32, 'rec'),
         _dev(x, torch.float32, 'x'), _ld(x), _dev(rel, torch.float32, 'rel'), _dev(loop_rel, torch.float32, 'loop_rel'),
         _dev(ee, torch.float32, 'ee', True), int(bool(ee_in_slot_order)), _dev(loop_edge, torch.float32, 'loop_edge', True),
         _dev(out, torch.float32, 'out') - out_row0 * _ld(out) * 4, _ld(out), n0, n1, hub_info, hub_chunks, hub_c0, hub_c1,
-        _dev(hub_partial, torch.float32, 'partial', True), ee_sub[0], ee_sub[1], ee_sub[2], _stream(x)), 'mgcn_aggregate_fwd')
+        _dev(hub_partial, torch.float32, 'partial', True), ee_sub[0], ee_sub[1], ee_sub[2], _stream(x))
+    if rc != 0 and hub_partial is not None:
+        _hub_failed(csr, D, x.device, n0, n1)
+    _check(rc, 'mgcn_aggregate_fwd')
     return out
 
 
@@ -287,9 +301,40 @@ def dense_bn_tanh_fwd(a, w_cat, bias, bn_mean, bn_var, bn_gamma, bn_beta, eps, o
     return out
 
 
-# `tune` argument of mgcn_layer_fwd_fused (include/mgcn_hip.h): 0 = automatic geometry. Read ONCE at import, for A/B tools
-# only: bits 0-3 row tiles per tile, 4-7 staging buffers, 8-9 relation table in LDS.
+# `tune` argument of mgcn_layer_fwd_fused (include/mgcn_hip.h): 0 = automatic. Read ONCE at import, for A/B tools only (see
+# INTEGRATION.md "Environment switches"): bits 0-3 row tiles per tile, 4-7 staging buffers / slots per batch, 8-9 relation
+# table in LDS, 10-11 a forced kernel generation (1 = 4, 2, 3), 12-13 columns per slot walk.
 FUSED_TUNE = int(os.environ.get('MGCN_FUSED_TUNE', '0'), 0)
+
+
+def tune_generation(tune=None):
+    """Kernel generation a `tune` word forces (0 = the shape's own)."""
+    f = ((FUSED_TUNE if tune is None else int(tune)) >> 10) & 3
+    return 0 if f == 0 else (4 if f == 1 else f)
+
+
+_FUSED_STATUS = {}
+
+
+def fused_status(device):
+    """The device's status word handed to every fused launch (mgcn_layer_fwd_fused status_dev): one int32, zero while no
+    bounded spin of the generation-3 kernel has run out."""
+    key = str(torch.device(device))
+    if key not in _FUSED_STATUS:
+        _FUSED_STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _FUSED_STATUS[key]
+
+
+def check_fused_status(device):
+    """Synchronising check of the status word (call where the host waits for results anyway: end of an evaluation, a
+    benchmark's timed region, tests): raises if a fused launch since the last check reported a spin timeout, and clears it."""
+    key = str(torch.device(device))
+    if key in _FUSED_STATUS:
+        v = int(_FUSED_STATUS[key].item())
+        if v:
+            _FUSED_STATUS[key].zero_()
+            raise NativeError('a fused layer launch on %s reported status %d: a bounded LDS-counter spin ran out '
+                              '(layer_fused3.hip), rows of that launch are invalid' % (key, v))
 FUSED_ENABLED = os.environ.get('MGCN_FUSED', '1') != '0'
 
 
@@ -308,19 +353,21 @@ def fused_supported(d_in, d_out):
     return FUSED_ENABLED and d_in % 4 == 0 and d_in <= 1024 and d_out % 4 == 0 and d_out <= 512
 
 
-def pack_weights(w_cat, out=None):
-    """Stacked [3D, O] weights -> MFMA fragment order for layer_fwd_fused (re-pack whenever a weight changes)."""
+def pack_weights(w_cat, out=None, generation=None):
+    """Stacked [3D, O] weights -> MFMA fragment order for layer_fwd_fused (re-pack whenever a weight changes).
+    `generation`: the kernel generation to pack for (None = what MGCN_FUSED_TUNE forces, else the shape's own)."""
     D, O = w_cat.size(0) // 3, w_cat.size(1)
     if w_cat.dim() != 2 or w_cat.size(0) != 3 * D or not w_cat.is_contiguous():
         raise NativeError('pack_weights: w_cat must be contiguous (3D, O)')
-    nbytes = lib().mgcn_packed_weights_bytes(D, O)
+    gen = tune_generation() if generation is None else int(generation)
+    nbytes = lib().mgcn_packed_weights_bytes_gen(gen, D, O)
     if out is None:
         out = torch.empty(nbytes // 4, dtype=torch.float32, device=w_cat.device)
     if out.numel() * 4 < nbytes:
         raise NativeError('pack_weights: out too small')
     _same_device(w_cat, out)
-    _check(lib().mgcn_pack_weights(D, O, _dev(w_cat, torch.float32, 'w_cat'), _dev(out, torch.float32, 'wp'),
-                                   out.numel() * 4, _stream(w_cat)), 'mgcn_pack_weights')
+    _check(lib().mgcn_pack_weights_gen(gen, D, O, _dev(w_cat, torch.float32, 'w_cat'), _dev(out, torch.float32, 'wp'),
+                                       out.numel() * 4, _stream(w_cat)), 'mgcn_pack_weights')
     return out
 
 
@@ -349,7 +396,8 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         if not ee_in_slot_order or tuple(ee.shape) != (sum(rows), D) or not ee.is_contiguous() or \
                 ee_sub != csr.shard_ee_sub(n0, n1):
             raise NativeError('layer_fwd_fused: per-edge shard does not match destinations [%d, %d)' % (n0, n1))
-    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes(D, O):
+    tune = FUSED_TUNE if tune is None else int(tune)
+    if not rel.is_contiguous() or w_packed.numel() * 4 < lib().mgcn_packed_weights_bytes_gen(tune_generation(tune), D, O):
         raise NativeError('layer_fwd_fused: rel must be contiguous and w_packed sized by mgcn_packed_weights_bytes')
     for v in (bn_mean, bn_var, bn_gamma, bn_beta) + ((bias,) if bias is not None else ()):
         if v.numel() != O:
@@ -381,7 +429,10 @@ def layer_fwd_fused(csr, x, rel, loop_rel, ee, ee_in_slot_order, loop_edge, w_pa
         hub_info, hub_chunks, hub_c0, hub_c1,
         _dev(hub_partial, torch.float32, 'partial', True), _dev(rels_weight, torch.float32, 'rels_weight', True),
         _dev(rel_out, torch.float32, 'rel_out', True), _dev(bounds, torch.int32, 'row_bounds', True),
-        bounds.numel() - 1 if bounds is not None else 0, FUSED_TUNE if tune is None else int(tune), _stream(x))
+        bounds.numel() - 1 if bounds is not None else 0, tune, _dev(fused_status(x.device), torch.int32, 'status'),
+        _stream(x))
+    if rc != 0 and hub_partial is not None:
+        _hub_failed(csr, D, x.device, n0, n1)
     if rc == 3:
         raise FusedUnsupported('mgcn_layer_fwd_fused: %s' % lib().mgcn_last_error().decode())
     _check(rc, 'mgcn_layer_fwd_fused')

@@ -205,14 +205,17 @@ constexpr int kFoldSpan = 16;
 // group waits for its stores to be acknowledged before its (memory-side) counter increment, and the last arriver's loads depend on the
 // increment's result. The last arriver puts the counter back to zero for the next launch.
 __device__ __forceinline__ bool hub_arrive(int32_t *counter, int expected, int lane_in_group, int gs) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // s_waitcnt vmcnt(0): this group's row stores are acknowledged
+  // This group's write-through (sc1) row stores must be ACKNOWLEDGED before the counter moves: the increment travels to another
+  // channel than the rows and may otherwise become visible first. A workgroup-scope release fence emits nothing for global memory
+  // on gfx950 (checked in the ISA), so the wait is written out; tests/test_host.py greps the device ISA for it.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int old = 0;
   if (lane_in_group == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = __shfl(old, 0, gs);
   if (old != expected - 1) return false;
   if (lane_in_group == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (compiler ordering: the row loads stay behind the increment)
-  return true;
+  asm volatile("" ::: "memory");                               // (compiler ordering: the sc1 row loads stay behind the increment,
+  return true;                                                 //  whose returned value the branch above depends on)
 }
 
 template <int VEC, int CPL>

@@ -1,6 +1,6 @@
 // Fused layer forward (eval) — C-ABI entry points: mgcn_pack_weights / mgcn_packed_weights_bytes /
 // mgcn_layer_fwd_fused (include/mgcn_hip.h (2)+(4)); replaces model.py:29-30, 99-107, 111-118 in one launch.
-// The kernels are layer_fused2.hip (D <= 256, O <= 208) and layer_fused3.hip (the rest).
+// The kernels are layer_fused2.hip (D <= 256, O <= 208), layer_fused3.hip (the rest) and, through `tune` only, layer_fused4.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -9,28 +9,57 @@
 
 
 namespace {
-// Two kernels behind one entry point. layer_fused2.hip (one workgroup barrier per stage: every workgroup walks the packed
-// weights in step, which keeps them L2-resident while the step's alternating layers stream 330 MB through the caches)
-// takes D <= 256, O <= 208; layer_fused3.hip (ring of staging buffers, O up to 512, 256-column passes) takes the rest.
+// Three kernels behind one entry point.
+//   generation 2  layer_fused2.hip  D <= 256, O <= 208: gather / multiply roles in lockstep, one workgroup barrier per stage (every
+//                 workgroup walks the packed weights in step, which keeps them L2-resident while the step's alternating layers
+//                 stream 330 MB through the caches): the benchmark's layers;
+//   generation 3  layer_fused3.hip  the rest (D <= 1024, O <= 512), and generation 2's shapes when the caller brings work-balanced
+//                 runs for a launch that is short of two tiles per CU (FB15k-237): roles coupled by LDS counters. Generations 2
+//                 and 3 share the k order, the six products and (O > 128) the weight packing: their rows are bit-identical
+//                 (tests/test_gpu_round4.py holds them to it at the benchmark's sizes);
+//   generation 4  layer_fused4.hip  D <= 256, O <= 208, round 4's structural experiment (no role split: sixteen waves gather, then
+//                 sixteen multiply; K folded): correct, NOT faster (LAB_NOTES.md) — reachable through `tune` only, own packing.
 bool lockstep_shape(int32_t dim_in, int32_t dim_out) { return dim_in <= 256 && mgcn::fused2_takes(dim_in, dim_out); }
+int pack_generation(int32_t dim_in, int32_t dim_out) { return lockstep_shape(dim_in, dim_out) ? 2 : 3; }
+bool generation_takes(int gen, int32_t dim_in, int32_t dim_out) {
+  if (gen == 4) return mgcn::fused4_takes(dim_in, dim_out);
+  if (gen == 2) return lockstep_shape(dim_in, dim_out);
+  return gen == 3 && mgcn::fused3_takes(dim_in, dim_out);
+}
 }  // namespace
 
+extern "C" size_t mgcn_packed_weights_bytes_gen(int32_t generation, int32_t dim_in, int32_t dim_out) {
+  const int gen = generation ? generation : pack_generation(dim_in, dim_out);
+  if (gen == 4) return mgcn::fused4_packed_bytes(dim_in, dim_out);
+  if (gen == 2) return mgcn::fused2_packed_bytes(dim_in, dim_out);
+  return mgcn::fused3_packed_bytes(dim_in, dim_out);
+}
+
 extern "C" size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out) {
-  return lockstep_shape(dim_in, dim_out) ? mgcn::fused2_packed_bytes(dim_in, dim_out) : mgcn::fused3_packed_bytes(dim_in, dim_out);
+  return mgcn_packed_weights_bytes_gen(0, dim_in, dim_out);
+}
+
+extern "C" int mgcn_pack_weights_gen(int32_t generation, int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev,
+                                     size_t wp_bytes, void *stream) {
+  MGCN_REQUIRE(dim_in > 0 && dim_out > 0 && w_dev && wp_dev, "pack_weights: bad arguments");
+  const int gen = generation ? generation : pack_generation(dim_in, dim_out);
+  MGCN_REQUIRE(gen >= 2 && gen <= 4 && generation_takes(gen, dim_in, dim_out),
+               "pack_weights: generation %d does not take D=%d O=%d", gen, dim_in, dim_out);
+  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes_gen(gen, dim_in, dim_out) && mgcn::aligned16(wp_dev),
+               "pack_weights: packed buffer too small or misaligned");
+  if (gen == 4) return mgcn::fused4_pack(dim_in, dim_out, w_dev, wp_dev, stream);
+  if (gen == 2) return mgcn::fused2_pack(dim_in, dim_out, w_dev, wp_dev, stream);
+  return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
 }
 
 extern "C" int mgcn_pack_weights(int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev, size_t wp_bytes,
                                  void *stream) {
-  MGCN_REQUIRE(dim_in > 0 && dim_out > 0 && w_dev && wp_dev, "pack_weights: bad arguments");
-  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes(dim_in, dim_out) && mgcn::aligned16(wp_dev),
-               "pack_weights: packed buffer too small or misaligned");
-  if (lockstep_shape(dim_in, dim_out)) return mgcn::fused2_pack(dim_in, dim_out, w_dev, wp_dev, stream);
-  return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
+  return mgcn_pack_weights_gen(0, dim_in, dim_out, w_dev, wp_dev, wp_bytes, stream);
 }
 
-// Which kernel a launch takes (2 = lockstep, layer_fused2.hip; 3 = elastic, layer_fused3.hip). Work-balanced runs are the elastic
-// kernel's: a lockstep shape takes it too when the lockstep tiling would leave the chip short of two tiles per CU (FB15k-237:
-// 228 tiles of 64 rows on 256 CUs, the heaviest tile 1.15x the mean) and the two packings coincide (O > 128).
+// Which kernel a launch takes when `tune` forces none (2 = lockstep, 3 = elastic). Work-balanced runs are the elastic kernel's: a
+// lockstep shape takes it too when the lockstep tiling would leave the chip short of two tiles per CU (FB15k-237: 228 tiles of
+// 64 rows on 256 CUs, the heaviest tile 1.15x the mean) and the two packings coincide (O > 128).
 extern "C" int mgcn_fused_kernel_generation(int32_t dim_in, int32_t dim_out, int64_t num_rows, int32_t with_row_bounds) {
   if (!lockstep_shape(dim_in, dim_out)) return 3;
   int cus = 256, dev = 0;
@@ -51,7 +80,7 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                     const int32_t *hubinfo_dev, const int32_t *chunks_dev, int64_t chunk_begin,
                                     int64_t chunk_end, float *partial_dev, const float *rels_weight_dev,
                                     float *rel_out_dev, const int32_t *row_bounds_dev, int32_t num_row_bounds,
-                                    int32_t tune, void *stream) {
+                                    int32_t tune, uint32_t *status_dev, void *stream) {
   MGCN_REQUIRE(num_nodes >= 0 && num_edges_half >= 0 && dim_in > 0 && dim_out > 0 && num_rel_rows > 0,
                "layer_fwd_fused: bad sizes");
   MGCN_REQUIRE(node_begin >= 0 && node_begin <= node_end && node_end <= num_nodes, "layer_fwd_fused: bad node range");
@@ -80,12 +109,25 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                            partial_dev, stream))
       return rc;
   }
-  // tune bits 10-11 = 3: the elastic kernel on a lockstep shape (A/B runs; the two packings coincide for O > 128 only)
-  const bool force3 = ((tune >> 10) & 3) == 3;
-  MGCN_REQUIRE(!force3 || dim_out > 128, "layer_fwd_fused: tune %d: the elastic kernel reads another packing for O <= 128", tune);
+  // tune bits 10-11: 0 = the launch's own kernel; 1 / 2 / 3 force generation 4 / 2 / 3 (A/B runs; wp_dev must be packed for it:
+  // mgcn_pack_weights_gen; generations 2 and 3 share one packing for O > 128)
+  const int forced = (tune >> 10) & 3;
+  const int gen = forced == 0 ? mgcn_fused_kernel_generation(dim_in, dim_out, node_end - node_begin, num_row_bounds > 0)
+                              : (forced == 1 ? 4 : forced);
+  MGCN_REQUIRE(forced != 3 || !lockstep_shape(dim_in, dim_out) || dim_out > 128,
+               "layer_fwd_fused: tune %d: generation 3 reads another packing than generation 2 for O <= 128", tune);
+  MGCN_REQUIRE(generation_takes(gen, dim_in, dim_out), "layer_fwd_fused: tune %d: generation %d does not take D=%d O=%d", tune, gen,
+               dim_in, dim_out);
   MGCN_REQUIRE(num_row_bounds >= 0 && num_row_bounds <= 4096 && (num_row_bounds == 0 || row_bounds_dev),
                "layer_fwd_fused: bad row bounds");
-  if (!force3 && mgcn_fused_kernel_generation(dim_in, dim_out, node_end - node_begin, num_row_bounds > 0) == 2)
+  if (gen == 4)
+    return mgcn::fused4_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
+                               loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
+                               bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
+                               num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
+                               want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, row_bounds_dev,
+                               num_row_bounds, tune, stream);
+  if (gen == 2)
     return mgcn::fused2_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
@@ -96,5 +138,5 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                                bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
                                num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
                                want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, row_bounds_dev,
-                               num_row_bounds, tune, stream);
+                               num_row_bounds, tune, status_dev, stream);
 }

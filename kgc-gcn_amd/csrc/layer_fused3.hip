@@ -34,7 +34,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T3 = 1024;
-constexpr int SPIN_LIMIT = 1 << 22;   // bounded spins: a protocol error ends in wrong numbers, never in a hung wave
+constexpr int SPIN_LIMIT = 1 << 22;   // bounded spins: a protocol error (or a wave parked by a debugger / preemption for ~0.1 s)
+                                      // never hangs a wave; it is REPORTED through Args3::status, the caller's status word
 
 struct Args3 {
   const int32_t *rowptr;
@@ -55,6 +56,7 @@ struct Args3 {
   int32_t npass, nkb_last, kbp, kbm, G;   // passes per mode, k-blocks of the last pass / of a full pass / per mode / per tile
   int32_t ncc;            // 16-byte chunk columns of a stage image (8 bf16 each)
   int32_t rows_per_wg, nimg;
+  uint32_t *status;        // optional: bit 0 is set when a bounded spin below ran out (the launch's rows are then invalid)
   const int32_t *bounds;   // [grid + 1] row offsets from node0 of the workgroups' runs (work-balanced), or null: equal runs
   float bn_eps;
 #ifdef MGCN_DIAG
@@ -97,13 +99,16 @@ __device__ __forceinline__ float4 f4axpy(float4 s, float4 m, float w) {
 
 // LDS counters: [0..3] rows staged per staging buffer, [4..7] buffer converted (free again), [8] one-time tables ready,
 // [9] MFMA waves that have converted their share of the current stage, [10] MFMA waves done multiplying a stage
-__device__ __forceinline__ void wait_ge_(const uint32_t *c, uint32_t need) {
+__device__ __forceinline__ void wait_ge_(const uint32_t *c, uint32_t need, uint32_t *status) {
+  int spins = 0;
 #pragma nounroll
-  for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
+  for (; spins < SPIN_LIMIT; ++spins) {
     const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if (v >= need) break;
     __builtin_amdgcn_s_sleep(1);
   }
+  // A spin that ran out: the wave goes on (it must, or its partners spin out too) and the tile it touches is garbage — say so.
+  if (spins == SPIN_LIMIT && status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void signal_add(uint32_t *c, int lane) {
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
   unsigned long long t_wait = 0, n_wait = 0, t_load = 0, n_load = 0, t_last = t_begin, t_a = 0, t_b = 0, t_d = 0, t_o = 0;
   auto wait_ge = [&](const uint32_t *c, uint32_t need) __attribute__((always_inline)) {
     const unsigned long long t0 = DIAG_NOW();
-    wait_ge_(c, need);
+    wait_ge_(c, need, p.status);
     t_wait += DIAG_NOW() - t0;
     ++n_wait;
   };
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(T3, 4) void layer_fused3_kernel(Args3 p) {
     }
   };
 #else
-  auto wait_ge = [](const uint32_t *c, uint32_t need) __attribute__((always_inline)) { wait_ge_(c, need); };
+  auto wait_ge = [&](const uint32_t *c, uint32_t need) __attribute__((always_inline)) { wait_ge_(c, need, p.status); };
   auto diag_end = [] () {};
 #endif
 
@@ -832,7 +837,7 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
                   const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
                   int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
                   const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, const int32_t *row_bounds_dev,
-                  int32_t num_row_bounds, int32_t tune, void *stream) {
+                  int32_t num_row_bounds, int32_t tune, uint32_t *status_dev, void *stream) {
   const int t_nch = (tune >> 12) & 3;
   if (t_nch > 2) return mgcn::fail(MGCN_EINVAL, "layer_fwd_fused: bad tune %d", tune);
   const Shape3 s = shape3(dim_in, t_nch);
@@ -849,6 +854,7 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   p.rw = rel_out_dev ? rels_weight_dev : nullptr; p.rel_out = rel_out_dev;
   p.npass = s.npass; p.nkb_last = s.nkb_last; p.kbp = s.kbp; p.kbm = s.kbm; p.G = s.G; p.ncc = s.ncc;
   p.bn_eps = bn_eps;
+  p.status = status_dev;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;

@@ -269,7 +269,8 @@ def test_hub_fold_inside_the_prepass_launch(pkg, oracle, D):
 def test_work_balanced_runs_do_not_change_rows(pkg, oracle, zipf):
     """mgcn_layer_fwd_fused's row_bounds_dev (GraphCSR.workgroup_bounds: one work-balanced run of destinations per CU):
     the elastic kernel's rows are bit-identical with and without them, for the whole graph and for a destination
-    range with its table shard, and match the oracle (model.py:82-109) like every other launch."""
+    range with its table shard, equal to the lockstep kernel's, and match the oracle; the experimental generation-4 kernel
+    (`tune` only) has the same invariances on its own bits (model.py:82-109) like every other launch."""
     N, R, E, D, O = 5000, 11, 60000, 100, 200
     ei, ea, csr = _graph(pkg, oracle, N, R, E, seed=9, zipf=zipf)
     conv = _layer(pkg, D, O, R, seed=4, bias=True)
@@ -280,13 +281,15 @@ def test_work_balanced_runs_do_not_change_rows(pkg, oracle, zipf):
     table = ee.index_select(0, csr.perm)
     nat = pkg._native
     bn = conv.ent_bn
-    _, wpack = conv.derived_weights()
+    wcat, _ = conv.derived_weights()
+    packs = {g: nat.pack_weights(wcat, generation=g) for g in (0, 4)}       # (generations 2 and 3 share the shape's own packing)
 
     def launch(balance, tune, rng=None):
         n0, n1 = rng or (0, N)
         out = torch.empty((n1 - n0, O), device=DEV)
         tab = table if rng is None else csr.edge_table_shard(table, n0, n1)
-        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), tab, True, conv.loop_edge.reshape(-1), wpack, O, conv.bias,
+        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), tab, True, conv.loop_edge.reshape(-1),
+                            packs[4 if nat.tune_generation(tune) == 4 else 0], O, conv.bias,
                             bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out, node_range=rng,
                             ee_sub=(0, 0, 0) if rng is None else csr.shard_ee_sub(n0, n1), tune=tune, balance=balance)
         return out
@@ -295,8 +298,13 @@ def test_work_balanced_runs_do_not_change_rows(pkg, oracle, zipf):
     plain = launch(False, 0xc00)                 # the elastic kernel, equal runs
     assert torch.equal(launch(True, 0xc00), plain)
     assert torch.equal(launch(True, 0), plain)   # 63 lockstep tiles < 2 x CUs: the balanced launch is the elastic kernel
+    assert torch.equal(launch(False, 0), plain)  # ... and the lockstep kernel's rows are the same bits
     part = launch(True, 0, (1234, 4321))
     assert torch.equal(part, plain[1234:4321])
+    g4 = launch(False, 0x400)                    # round 4's experimental kernel: its own k order, its own bits, same invariances
+    assert torch.equal(launch(True, 0x400), g4) and torch.equal(launch(True, 0x400, (1234, 4321)), g4[1234:4321])
+    assert torch.equal(launch(False, 0x1404), g4) and torch.equal(launch(False, 0x3423), g4)   # tile heights, batch depth, stagger
+    assert float((g4 - plain).abs().max()) < 2e-6
     sd = {'conv1.' + k: v.detach().cpu() for k, v in conv.state_dict().items()}
     want, _ = oracle.layer_forward(sd, 'conv1.', x.cpu(), ei, ea[0], ee.cpu(), rel.cpu(), training=False)
     np.testing.assert_allclose(plain.cpu().numpy(), want.numpy(), rtol=0, atol=2e-4 if zipf else 5e-5)

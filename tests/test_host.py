@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol(pkg):
     handle = ctypes.CDLL(pkg._native.LIB_PATH)
     for name in declared:
         assert hasattr(handle, name), name
-    assert pkg._native.lib().mgcn_abi_version() == 3
+    assert pkg._native.lib().mgcn_abi_version() == 4
 
 
 @pytest.mark.parametrize('case', ALL_CASES)
@@ -474,7 +474,7 @@ def test_abi_argument_validation_without_a_gpu(pkg):
         ('mgcn_aggregate_bwd', (4, 2, 0, 3, N, N, N, N, N, N, 0, N, N, N, 4, N, N, N, 8, N, N, N, N, 0, N), 'bad sizes'),
         ('mgcn_dense_bn_tanh_fwd', (4, 4, 4, N, 12, N, N, N, N, N, N, 1e-5, N, 4, N), 'null pointer'),
         ('mgcn_layer_fwd_fused', (4, 2, 4, 4, 3, N, N, N, 4, N, N, N, 1, N, N, N, N, N, N, N, 1e-5, N, 4, 2, 1, 0, 0, 0, N, N, 0,
-                                  0, N, N, N, N, 0, 0, N), 'bad node range'),
+                                  0, N, N, N, N, 0, 0, N, N), 'bad node range'),
         ('mgcn_score_fwd', (4, 8, 4, N, 4, N, 4, N, N, 8, N), 'null pointer'),
         ('mgcn_score_rank', (4, 8, 0, 4, N, 4, N, 4, N, N, N, N, 0, N, 0, N, N), 'null pointer'),
         ('mgcn_filter_mask', (4, N, 0, N, N, N, 0, 8, N, 1, N), 'null pointer'),
@@ -618,11 +618,16 @@ def test_workgroup_bounds_balance_the_work(pkg):
 
 
 def test_fused_kernel_generation_rule(pkg):
-    """mgcn_fused_kernel_generation (no device work): wide shapes take the elastic kernel; a lockstep shape takes it too
-    when the caller brings work-balanced runs, its lockstep tiling has fewer than two tiles per CU and O > 128
-    (FB15k-237: 182 tiles of 80 rows), and stays on the lockstep kernel otherwise (WN18RR: 512 tiles)."""
+    """mgcn_fused_kernel_generation (no device work): wide shapes take the elastic kernel (generation 3); a lockstep shape
+    takes it too when the caller brings work-balanced runs, its lockstep tiling has fewer than two tiles per CU and O > 128
+    (FB15k-237: 182 tiles of 80 rows), and stays on the lockstep kernel (generation 2) otherwise (WN18RR: 512 tiles).
+    Generation 4 (round 4's experiment) is never dispatched: `tune` only. Packing sizes per generation."""
     gen = pkg._native.lib().mgcn_fused_kernel_generation
     assert gen(100, 200, 40943, 1) == 2 and gen(200, 200, 40943, 0) == 2
     assert gen(100, 200, 14541, 1) == 3 and gen(100, 200, 14541, 0) == 2
     assert gen(100, 64, 14541, 1) == 2                      # O <= 128: the two kernels read different packings
     assert gen(512, 512, 250000, 0) == 3 and gen(512, 200, 250000, 1) == 3 and gen(200, 256, 40943, 0) == 3
+    nb = pkg._native.lib().mgcn_packed_weights_bytes_gen
+    assert nb(0, 100, 200) == nb(2, 100, 200) == nb(3, 100, 200) == 12 * 13 * 3 * 64 * 16    # generations 2 and 3: one packing
+    assert nb(4, 100, 200) == 10 * 13 * 3 * 64 * 16 and nb(4, 200, 200) == 19 * 13 * 3 * 64 * 16   # K = 3 D padded ONCE
+    assert nb(0, 512, 512) == nb(3, 512, 512)

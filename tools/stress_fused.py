@@ -66,6 +66,27 @@ def run(seed=0, trials=60, keep_going=False, wide=False):
                                 bn.bias, bn.eps, part, node_range=(n0, n1), ee_sub=csr.shard_ee_sub(n0, n1))
             if not torch.equal(part, out[n0:n1]): why += ' range[%d,%d)' % (n0, n1)
             ok = ok and torch.equal(part, out[n0:n1])
+            # round 4's experimental kernel (generation 4, `tune` only): within 2e-6 of the dispatched kernel, and bit-identical to
+            # itself across tile geometries, batch depths, stagger groups and a destination range
+            if N and D <= 256 and O <= 208:
+                wp4 = nat.pack_weights(conv.derived_weights()[0], generation=4)
+                def g4(tune, rng_=None):
+                    a, b = rng_ or (0, N)
+                    o4 = torch.empty((b - a, O), device=dev)
+                    nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), table if rng_ is None else csr.edge_table_shard(table, a, b),
+                                        True, conv.loop_edge.reshape(-1), wp4, O, conv.bias, bn.running_mean, bn.running_var, bn.weight,
+                                        bn.bias, bn.eps, o4, tune=tune, node_range=rng_, ee_sub=(0, 0, 0) if rng_ is None else csr.shard_ee_sub(a, b))
+                    return o4
+                base4 = g4(0x400)
+                tune = 0x400 | int(rng.choice([3, 4, 5])) | (int(rng.choice([2, 4] if D <= 128 else [2])) << 4) | (int(rng.choice([0, 1])) << 8) | (int(rng.choice([0, 1, 2, 3])) << 12)
+                d4 = float((base4 - out).abs().max())
+                try:
+                    same = torch.equal(g4(tune), base4) and torch.equal(g4(0x400, (n0, n1)), base4[n0:n1])
+                except nat.NativeError as e:
+                    if 'does not fit' not in str(e): raise
+                    same = True
+                if d4 >= 2e-6 or not same: why += ' gen4(tune %#x, %.1e)' % (tune, d4)
+                ok = ok and d4 < 2e-6 and same
         else:
             ok = True; why = ''
         # oracle (CPU): layer output in the reference's order
