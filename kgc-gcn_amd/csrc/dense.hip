@@ -896,7 +896,7 @@ extern "C" int mgcn_matmul_f32(int64_t m, int32_t k, int32_t n, const float *a_d
   MGCN_REQUIRE(a_dev && b_dev && c_dev, "matmul_f32: null pointer");
   MGCN_REQUIRE(lda >= k && ldb >= n && ldc >= n, "matmul_f32: leading dimension too small");
   if (m == 0 || n == 0) return MGCN_OK;
-  if (m <= 1024 && n <= 4096) {  // relation projection: a few dozen rows, latency bound
+  if (m <= 1024 && n <= 4096 && k <= 2048) {  // relation projection: a few dozen rows, latency bound (a long K is the tile kernel's)
     hipLaunchKernelGGL(small_matmul_kernel, dim3(unsigned(m), unsigned((n + 63) / 64)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a_dev, lda, b_dev, ldb, c_dev, ldc, k, n);
     MGCN_CHECK_LAUNCH("small_matmul_kernel");

@@ -48,15 +48,39 @@ class FilterIndex(object):
         return sub.to(torch.int64) * self.num_rel_ids + rel.to(torch.int64)
 
 
+_INTO_TENSOR = {}
+
+
+def _into_tensor_ok(group, like):
+    """Whether the group's backend has all_gather_into_tensor — decided ONCE per (backend, device type) by a one-element probe
+    that every rank of the group runs at the same point (the first exchange), never by catching an error of a real
+    collective: a rank whose collective fails for its own reasons (an RCCL error, a size mismatch) must raise, not
+    quietly switch to another collective than its peers are in."""
+    key = (dist.get_backend(group), like.device.type)
+    if key not in _INTO_TENSOR:
+        ok = hasattr(dist, 'all_gather_into_tensor')
+        if ok:
+            world = dist.get_world_size(group)
+            try:
+                dist.all_gather_into_tensor(like.new_zeros(world), like.new_zeros(1), group=group)
+            except (RuntimeError, NotImplementedError):   # a capability of the backend: the same answer on every rank
+                ok = False
+        _INTO_TENSOR[key] = ok
+    return _INTO_TENSOR[key]
+
+
 def _gather_into(out, t, group):
     """out [world * n, ...] <- every rank's t [n, ...], in rank order: ONE collective writing straight into `out`
     (all_gather_into_tensor; the list form costs a staging copy per rank on RCCL — 20.5 GB per layer at BASELINE
-    configs[4]). Backends without it (old gloo builds) take the list form over views of `out`."""
+    configs[4]). Backends without it take the list form over views of `out`. Every rank passes the same n; n = 0 is no
+    collective at all (nothing to exchange, on any rank). Errors of the collective propagate."""
     t = t.contiguous()
-    try:
+    if t.size(0) == 0:
+        return out
+    if _into_tensor_ok(group, t):
         dist.all_gather_into_tensor(out, t, group=group)
-    except (RuntimeError, NotImplementedError):
-        dist.all_gather(list(out.chunk(out.size(0) // max(t.size(0), 1), dim=0)) if t.size(0) else [], t, group=group)
+    else:
+        dist.all_gather(list(out.chunk(out.size(0) // t.size(0), dim=0)), t, group=group)
     return out
 
 
@@ -212,21 +236,38 @@ def encode_sharded(model, graph, group=None):
 
 
 @torch.no_grad()
-def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, trunk_chunk=2048, shard_encoder=False):
+def evaluate_sharded(model, graph, queries, filt, batch_size=None, group=None, trunk_chunk=2048, shard_encoder=False,
+                     parts=None):
     """Filtered MR / MRR / hits@{1,3,10} of `queries` ([Q, 3] int64: subject, relation id, object; both directions
     already expanded, as the loader's *_tail + *_head lists) with the entity table sharded over the group.
 
     Rank r owns the contiguous query range [c_r, c_{r+1}) (padded to a common length so every rank runs the same
     collectives). The queries go to the device once, the ConvE trunk runs over them in chunks of `trunk_chunk`, and the
     exchange happens ONCE for the whole evaluation: one all-gather of the query embeddings / keys / objects, one
-    all-reduce of the target scores, one all-reduce of the integer counts. `batch_size` only sets how many queries one
-    score + filter + count launch takes (None = all of them); the result does not depend on it. `shard_encoder=True`
-    also partitions the encoder by destination (encode_sharded)."""
+    all-reduce of the target scores, one all-reduce of the integer counts. The score + filter + count kernel takes ALL
+    queries in one launch whenever their filter bits fit 512 MB (one launch of 6 268 queries costs 0.8 ms, 49 launches
+    of 128 cost 1.6 ms; the result does not depend on the split); `batch_size` forces blocks of that many queries (the
+    reference's 128, main.py:117, for like-for-like timing). `shard_encoder=True` also partitions the encoder by
+    destination (encode_sharded). `parts`: a dict that receives the wall-clock seconds of the encoder, the ConvE trunk
+    (stock torch, out of scope), the exchange and the HIP kernels — it adds a device synchronisation per part, so the
+    evaluation's total is NOT to be timed with it."""
+    import time
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model.eval()
+    clock = [None]
+
+    def lap(name):
+        if parts is not None:
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
+            now = time.perf_counter()
+            if clock[0] is not None and name is not None:
+                parts[name] = parts.get(name, 0.0) + now - clock[0]
+            clock[0] = now
+    lap(None)
     # encoder: replicated (default; 12-33 MB of output at FB15k-237 / WN18RR) or destination-partitioned
     all_ent, all_rel = encode_sharded(model, graph, group) if shard_encoder else model.encode(graph)
+    lap('encoder_s')
     N = all_ent.size(0)
     b = shard_bounds(N, world)
     ent_shard = all_ent[b[rank]:b[rank + 1]].contiguous()
@@ -243,22 +284,26 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
                                      all_rel.index_select(0, rel[i:i + trunk_chunk]))
                    for i in range(0, per, trunk_chunk)], dim=0) if per > 0 else all_ent.new_zeros((0, all_ent.size(1)))
     keys = filt.query_keys(sub, rel)
+    lap('trunk_s')
     if world > 1:       # every rank's (padded) queries to every rank, once
         x_all, key_all, obj_all = _gather(x, group, world), _gather(keys, group, world), _gather(obj, group, world)
     else:
         x_all, key_all, obj_all = x.contiguous(), keys, obj
+    lap('exchange_s')
     total, n_local = x_all.size(0), ent_shard.size(0)
     target = torch.zeros(total, dtype=torch.float32, device=dev)
     counts = torch.zeros((total, 3), dtype=torch.int64, device=dev)
     if total > 0 and n_local > 0:
         _native.score_target(x_all, ent_shard, bias_shard, obj_all, ent_row0=b[rank], out=target)
+    lap('kernels_s')
     if world > 1:
         dist.all_reduce(target, op=dist.ReduceOp.SUM, group=group)   # exactly one rank holds each target entity
-    step = total if not batch_size else int(batch_size)
+    lap('exchange_s')
     words = (n_local + 31) // 32
-    whole = total * words * 4 <= (512 << 20)                   # filter bits of all queries at once when they fit
+    fit = max(1, (512 << 20) // max(words * 4, 1))             # queries whose filter bits fit the budget at once
+    step = min(total, fit) if not batch_size else int(batch_size)
     mask_all = _native.filter_mask(key_all, filt.keys, filt.ptr, filt.tails, n_local, ent_row0=b[rank]) \
-        if (whole and total > 0 and n_local > 0) else None
+        if (total <= fit and total > 0 and n_local > 0) else None
     for i in range(0, total, max(step, 1)):
         if n_local == 0:
             break
@@ -266,8 +311,10 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
             key_all[i:i + step], filt.keys, filt.ptr, filt.tails, n_local, ent_row0=b[rank])
         _native.score_rank(x_all[i:i + step], ent_shard, bias_shard, obj_all[i:i + step], target[i:i + step], mask=mask,
                            ent_row0=b[rank], counts=counts[i:i + step])
+    lap('kernels_s')
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    lap('exchange_s')
     mine = counts[rank * per:(rank + 1) * per]
     ranks = (1 + mine[:, 0] + mine[:, 1]).double()[:real]
     sums = torch.zeros(13, dtype=torch.float64, device=dev)    # count, sum rank, sum 1/rank, hits@1..10
@@ -279,6 +326,9 @@ def evaluate_sharded(model, graph, queries, filt, batch_size=128, group=None, tr
     if world > 1:
         dist.all_reduce(sums, group=group)
     sums = sums.tolist()
+    lap('metrics_s')
+    if dev.type == 'cuda':
+        _native.check_fused_status(dev)         # (the host has just waited for the results: the fused launches' status word)
     count = sums[0]
     res = {'count': count, 'mr': sums[1] / count, 'mrr': sums[2] / count}
     for k in (1, 3, 10):

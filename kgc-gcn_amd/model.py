@@ -115,8 +115,15 @@ class _ScoreFn(torch.autograd.Function):
     def backward(ctx, gs):
         x, ent, s = ctx.saved_tensors
         gz = (gs * s * (1.0 - s)).contiguous()
-        return (_native.matmul(gz, ent.contiguous()) if ctx.needs_input_grad[0] else None,
-                _native.matmul(gz.t().contiguous(), x.contiguous()) if ctx.needs_input_grad[1] else None,
+        gzt = gz.t().contiguous() if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # gx = gz [B, N] @ ent [N, O]: the reduction runs over the N entities, so it goes to the split-K transposed kernel
+            # (K = N rows over <= 256 workgroups, partial products folded in order) — not to mgcn_matmul_f32's small-matrix
+            # kernel, whose one lane would walk all N terms in one sequential chain
+            gx = _native.matmul_tn(gzt, ent.contiguous()) if _native.matmul_tn_supported(gz.size(0), ent.size(1)) \
+                else _native.matmul(gz, ent.contiguous())
+        return (gx, _native.matmul(gzt, x.contiguous()) if ctx.needs_input_grad[1] else None,
                 gz.sum(0) if ctx.needs_input_grad[2] else None)
 
 

@@ -1,0 +1,199 @@
+"""Round-4 parity additions (`-m gpu`), closing the holes VERDICT r3 names:
+
+* configs[3]'s OWN split: FB15k-237's 14 541 entities in 8 row shards of 1 818 rows (not a multiple of the 32-row filter
+  word, the last shard shorter), B = 128, O = 200, played by one process through `ent_row0` — filter bits and dense labels —
+  with targets and counts `torch.equal` to the unsharded launch (main.py:122-126 on a row-sharded entity table);
+* generation 2 == generation 3 of the fused layer as a STATED invariant at the benchmark's sizes (WN18RR, D = 100 and 200):
+  a rank's destination range is sent to the elastic kernel while the one-GPU launch of the same graph stays on the lockstep
+  kernel, so "sharded == unsharded" rests on it (model.py:82-118 through either kernel);
+* the hub chunk-sum buffer after a FAILED launch: its arrival counters may be left non-zero, which would silently switch
+  the next launch's fold off — the error path forgets the buffer (kgc-gcn_amd/_native.py _hub_failed);
+* the fused launches' status word stays zero (layer_fused3.hip's bounded spins never ran out) and is checked by
+  check_fused_status; the score backward's N-long reduction runs on the split-K kernel at N = 40 943.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _bits_to_labels(mask, n):
+    bits = (mask.view(torch.int32)[:, :, None] >> torch.arange(32, device=mask.device, dtype=torch.int32)) & 1
+    return bits.reshape(mask.size(0), -1)[:, :n].float().contiguous()
+
+
+def test_fb15k237_scoring_in_eight_row_shards_equals_unsharded(pkg):
+    """BASELINE configs[3] exactly as it splits: 14 541 = 7 x 1 818 + 1 815 rows. Rank r's launches see only its shard of the
+    entity table / bias / filter columns and the global row offset; integer counts and the one non-zero target per query
+    add up to the unsharded launch's bit for bit, with filter bits and with dense label columns."""
+    nat, dist = pkg._native, pkg.dist
+    N, O, B, W, R = 14541, 200, 128, 8, 237
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, O, generator=g) * 0.4).to(DEV)
+    ent = (torch.randn(N, O, generator=g) * 0.3).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    rng = np.random.default_rng(5)
+    sub, rel, obj = rng.integers(0, N, B), rng.integers(0, 2 * R, B), rng.integers(0, N, B)
+    known = {}
+    for s_, r_, o_ in zip(sub, rel, obj):
+        known.setdefault((int(s_), int(r_)), set()).add(int(o_))
+        for t in rng.integers(0, N, 6):                      # a handful of other known tails per query, anywhere in the table
+            known[(int(s_), int(r_))].add(int(t))
+    for s_, r_ in zip(sub[:16], rel[:16]):                   # ... and tails right at the shard seams (rows 1817, 1818, 3635, ...)
+        for w in range(1, W):
+            known[(int(s_), int(r_))].update((w * 1818 - 1, w * 1818))
+    filt = dist.FilterIndex.from_known(known, 2 * R).to(DEV)
+    keys = filt.query_keys(torch.from_numpy(sub).to(DEV), torch.from_numpy(rel).to(DEV))
+    objd = torch.from_numpy(obj).to(DEV)
+    b = dist.shard_bounds(N, W)
+    assert b == [0, 1818, 3636, 5454, 7272, 9090, 10908, 12726, 14541] and 1818 % 32 != 0
+    # unsharded
+    target = nat.score_target(x, ent, bias, objd)
+    mask = nat.filter_mask(keys, filt.keys, filt.ptr, filt.tails, N)
+    counts = nat.score_rank(x, ent, bias, objd, target, mask=mask)
+    labels = _bits_to_labels(mask, N)
+    assert torch.equal(nat.score_rank(x, ent, bias, objd, target, label=labels), counts)
+    assert int(labels.sum()) >= 7 * B
+    # eight ranks in one process
+    t8 = torch.zeros(B, device=DEV)
+    for r in range(W):
+        nat.score_target(x, ent[b[r]:b[r + 1]].contiguous(), bias[b[r]:b[r + 1]].contiguous(), objd, ent_row0=b[r], out=t8)
+    assert torch.equal(t8, target)
+    c_bits = torch.zeros((B, 3), dtype=torch.int64, device=DEV)
+    c_dense = torch.zeros_like(c_bits)
+    for r in range(W):
+        es, bs = ent[b[r]:b[r + 1]].contiguous(), bias[b[r]:b[r + 1]].contiguous()
+        m = nat.filter_mask(keys, filt.keys, filt.ptr, filt.tails, b[r + 1] - b[r], ent_row0=b[r])
+        assert torch.equal(_bits_to_labels(m, b[r + 1] - b[r]), labels[:, b[r]:b[r + 1]])      # the shard's filter columns
+        nat.score_rank(x, es, bs, objd, t8, mask=m, ent_row0=b[r], counts=c_bits)
+        nat.score_rank(x, es, bs, objd, t8, label=labels[:, b[r]:b[r + 1]].contiguous(), ent_row0=b[r], counts=c_dense)
+    assert torch.equal(c_bits, counts) and torch.equal(c_dense, counts)
+    # the same through the sharding helper (world 1: one "rank" holding everything)
+    c1, t1 = dist.sharded_rank_counts(x, keys, objd, ent, bias, 0, filt)
+    assert torch.equal(c1, counts) and torch.equal(t1, target)
+
+
+@pytest.mark.parametrize('D', [100, 200])
+def test_lockstep_and_elastic_kernels_give_the_same_bits_at_wn18rr_size(pkg, oracle, D):
+    """mgcn_fused_kernel_generation sends the whole WN18RR graph to the lockstep kernel (generation 2) and a rank's destination
+    range with row bounds to the elastic one (generation 3): the two must be the same function bit for bit. Whole graph through
+    both, and a third of the graph (with its table shard) through both, at the benchmark's widths."""
+    N, R, E, O = 40943, 11, 86835, 200
+    tri = oracle.synthetic_triples(N, R, E, seed=0, zipf=0.0)
+    ei, ea = oracle.build_edge_list(tri, R)
+    csr = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei), torch.from_numpy(ea)[0], torch.device(DEV))
+    torch.manual_seed(D)
+    conv = pkg.MGCNConv(D, O, 2 * R, bias=True).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        conv.ent_bn.running_mean.copy_(torch.randn(O, generator=g) * 0.05)
+        conv.ent_bn.running_var.copy_(torch.rand(O, generator=g) * 0.5 + 0.05)
+        conv.bias.copy_(torch.randn(O, generator=g) * 0.1)
+    x = (torch.randn(N, D, generator=g) * 0.4).to(DEV)
+    rel = (torch.randn(2 * R, D, generator=g) * 0.5).to(DEV)
+    table = (torch.randn(2 * E, D, generator=g) * 0.5).to(DEV)      # slot order
+    nat, bn = pkg._native, conv.ent_bn
+    _, wpack = conv.derived_weights()
+    lib = nat.lib()
+    assert lib.mgcn_fused_kernel_generation(D, O, N, 0) == 2 and lib.mgcn_fused_kernel_generation(D, O, N // 3, 1) == 3
+
+    def launch(tune, balance, rng=None):
+        n0, n1 = rng or (0, N)
+        out = torch.full((n1 - n0, O), float('nan'), device=DEV)
+        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), table if rng is None else csr.edge_table_shard(table, n0, n1),
+                            True, conv.loop_edge.reshape(-1), wpack, O, conv.bias, bn.running_mean, bn.running_var, bn.weight,
+                            bn.bias, bn.eps, out, node_range=rng, ee_sub=(0, 0, 0) if rng is None else csr.shard_ee_sub(n0, n1),
+                            tune=tune, balance=balance)
+        return out
+    with torch.no_grad():
+        lock = launch(0, False)                    # generation 2, what the one-GPU step runs
+        elastic = launch(0xc00, True)              # generation 3 forced, balanced runs
+        assert torch.isfinite(lock).all() and float(lock.abs().mean()) > 0.05
+        assert torch.equal(lock, elastic)
+        third = (N // 3 + 5, 2 * (N // 3) + 11)
+        assert torch.equal(launch(0, True, third), lock[third[0]:third[1]])        # the dispatch a rank of three gets
+        assert torch.equal(launch(0x800, False, third), lock[third[0]:third[1]])   # ... and the lockstep kernel on that range
+    nat.check_fused_status(DEV)
+
+
+def test_failed_hub_launch_does_not_poison_the_next_one(pkg, oracle):
+    """A launch error between the hub pre-pass and the layer's launch (or an aborted pre-pass) may leave the fold's arrival
+    counters non-zero; the buffer is cached per graph, so every later fold on it would silently never fire. The error path
+    drops the cache entry. Simulated the hard way: poison the counters, make the next launch fail (a `tune` that fits no
+    geometry), and require the launch after that to be right again."""
+    N, R, E, D, O = 3000, 7, 60000, 100, 200
+    tri = oracle.synthetic_triples(N, R, E, seed=4, zipf=1.3)
+    ei, ea = oracle.build_edge_list(tri, R)
+    csr = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei), torch.from_numpy(ea)[0], torch.device(DEV))
+    assert csr.num_chunks > 8
+    torch.manual_seed(0)
+    conv = pkg.MGCNConv(D, O, 2 * R).to(DEV).eval()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(N, D, generator=g) * 0.4).to(DEV)
+    rel = (torch.randn(2 * R, D, generator=g) * 0.5).to(DEV)
+    table = (torch.randn(2 * E, D, generator=g) * 0.5).to(DEV)
+    nat, bn = pkg._native, conv.ent_bn
+    _, wpack = conv.derived_weights()
+
+    def launch(tune=0):
+        out = torch.empty((N, O), device=DEV)
+        nat.layer_fwd_fused(csr, x, rel, conv.loop_rel.reshape(-1), table, True, conv.loop_edge.reshape(-1), wpack, O, conv.bias,
+                            bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.eps, out, tune=tune)
+        return out
+    with torch.no_grad():
+        good = launch()
+        cache = csr.__dict__['_hub_partials']
+        assert len(cache) == 1
+        (key, (buf, _stream)), = cache.items()
+        nchunks = csr.chunk_range(0, N)[1] - csr.chunk_range(0, N)[0]
+        assert buf.numel() == nchunks * D + 2 * nchunks
+        counters = buf[nchunks * D:].view(torch.int32)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0                      # a completed launch leaves the counters zero
+        counters.fill_(3)                                          # an aborted fold's leftovers
+        bad = launch()                                             # (what the poison does when nothing repairs it: hubs lose their fold)
+        assert not torch.equal(bad, good)
+        counters.fill_(3)
+        with pytest.raises(nat.NativeError):
+            launch(tune=0xc00 | 0x0f5)                             # the elastic kernel with 15 staging buffers: fits no LDS -> MGCN_EINVAL
+        assert key not in csr.__dict__['_hub_partials']            # the error path forgot the poisoned buffer
+        again = launch()
+        assert torch.equal(again, good)
+        torch.cuda.synchronize()
+        fresh = csr.__dict__['_hub_partials'][key][0]
+        assert fresh.data_ptr() != buf.data_ptr() or int(fresh[nchunks * D:].view(torch.int32).abs().sum()) == 0
+    nat.check_fused_status(DEV)
+
+
+def test_status_word_is_checked_and_cleared(pkg):
+    """_native.check_fused_status: the word every fused launch is handed stays zero in normal operation; a non-zero word
+    (here: set by hand, standing in for a spin that ran out in layer_fused3.hip) raises once and is cleared."""
+    nat = pkg._native
+    word = nat.fused_status(DEV)
+    torch.cuda.synchronize()
+    nat.check_fused_status(DEV)
+    word.fill_(1)
+    with pytest.raises(nat.NativeError, match='spin'):
+        nat.check_fused_status(DEV)
+    nat.check_fused_status(DEV)                                    # cleared by the failed check
+    assert int(word.item()) == 0
+
+
+def test_score_backward_at_full_entity_count(pkg):
+    """gx = gz [B, N] @ ent [N, O] reduces over N = 40 943 entities; it runs on the split-K kernel, and matches
+    float64 autograd through sigmoid(x ent^T + bias) (model.py:177-179) to f32 roundoff."""
+    B, N, O = 128, 40943, 200
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, O, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    ent = (torch.randn(N, O, generator=g) * 0.2).to(DEV).requires_grad_(True)
+    bias = (torch.randn(N, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    gs = (torch.randn(B, N, generator=g) * 1e-3).to(DEV)
+    s = pkg.model._ScoreFn.apply(x, ent, bias)
+    s.backward(gs)
+    x64, e64, b64 = (t.detach().double().requires_grad_(True) for t in (x, ent, bias))
+    torch.sigmoid(x64 @ e64.t() + b64).backward(gs.double())
+    for got, want, name in ((x.grad, x64.grad, 'x'), (ent.grad, e64.grad, 'ent'), (bias.grad, b64.grad, 'bias')):
+        scale = float(want.abs().max())
+        assert float((got.double() - want).abs().max()) <= 2e-5 * scale + 1e-12, name

@@ -631,3 +631,41 @@ def test_fused_kernel_generation_rule(pkg):
     assert nb(0, 100, 200) == nb(2, 100, 200) == nb(3, 100, 200) == 12 * 13 * 3 * 64 * 16    # generations 2 and 3: one packing
     assert nb(4, 100, 200) == 10 * 13 * 3 * 64 * 16 and nb(4, 200, 200) == 19 * 13 * 3 * 64 * 16   # K = 3 D padded ONCE
     assert nb(0, 512, 512) == nb(3, 512, 512)
+
+
+def test_hub_fold_waits_for_its_row_stores_before_the_counter(pkg, tmp_path):
+    """in agg_hub_kernel the write-through (sc1) chunk-sum / span-total stores must be acknowledged before
+    the agent-scope counter increment that tells the last arriver to read them; a workgroup-scope release fence emits no
+    wait for global memory on gfx950, so the wait is written out — checked here in the device ISA: between any vector
+    store and a following global_atomic_add there is an `s_waitcnt vmcnt(0)`."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'kgc-gcn_amd', 'csrc', 'aggregate.hip')
+    asm = str(tmp_path / 'aggregate.s')
+    subprocess.run([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-S', '--cuda-device-only', '-o', asm,
+                    src], check=True, cwd=str(tmp_path), stderr=subprocess.DEVNULL)
+    kernels, cur = {}, None
+    for line in open(asm):
+        m = re.match(r'^(_Z\w*agg_hub_kernel\w*):', line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif line.startswith('.Lfunc_end'):
+            cur = None
+        elif cur is not None:
+            cur.append(line.strip())
+    assert kernels, 'no agg_hub_kernel in the ISA'
+    for name, body in kernels.items():
+        atomics = [i for i, l in enumerate(body) if l.startswith('global_atomic_add')]
+        assert atomics, name
+        for i in atomics:
+            waited = False
+            for l in reversed(body[:i]):            # walk back to the previous vector-memory store: a full wait must come first
+                if re.match(r's_waitcnt vmcnt\(0\)', l):
+                    waited = True
+                    break
+                if l.startswith(('global_store', 'global_atomic', 'scratch_store', 'buffer_store')):
+                    break
+            assert waited, '%s: global_atomic_add at ISA line %d is not behind s_waitcnt vmcnt(0)' % (name, i)
