@@ -408,10 +408,15 @@ def config5_slice(pkg, dev, world, rank, dist, N=2000000, E=20000000, R=1000, D=
     # compulsory bytes of the rank's share: its per-edge rows + records, the x rows its slots gather (the 4 GB table is far
     # past every cache, so a gathered row is a DRAM access), its own x rows, its output rows
     gathered = rows * (4 * D + 4 * D + 16) + (n1 - n0) * (4 * D + 4 * O)
+    # SURVEY 8(d)'s compulsory bytes of the same launch (every distinct byte once: the layer input counted ONCE, not per slot):
+    # the contract's roofline fraction; the gathered-bytes fraction beside it says how fast real DRAM traffic moves
+    bytes_8d = rows * (4 * D + 8) + 2 * (n1 - n0 + 1) * 4 + N * 4 * D + (2 * R + 1) * 4 * D + 16 * D * O + (n1 - n0) * 4 * O
     res = {'graph': 'N=%d E=%d R=%d dim %d->%d, slice %d of %d' % (N, E, R, D, O, part, parts), 'slots_this_rank': rows,
            'table_shard_GB': table.numel() * 4 / 1e9, 'whole_table_GB': 2 * E * D * 4 / 1e9, 'layer_ms': ms,
-           'edges_per_s_per_rank': (rows + (n1 - n0)) / ms * 1e3, 'gathered_GBps': gathered / ms / 1e6,
-           'frac_of_8TBps': gathered / ms / 1e6 / HBM_PEAK_GBS,
+           'edges_per_s_per_rank': (rows + (n1 - n0)) / ms * 1e3,
+           'bytes_8d_GB': bytes_8d / 1e9, 'frac_8d_of_8TBps': bytes_8d / ms / 1e6 / HBM_PEAK_GBS,
+           'gathered_GBps': gathered / ms / 1e6, 'frac_gathered_of_8TBps': gathered / ms / 1e6 / HBM_PEAK_GBS,
+           'full_size': 'profiles/r04_scale_shard_full.json: rank 0 of 8 of the TRUE 10M / 100M / dim-512 graph (tools/bench_scale_shard.py)',
            'path': 'fused' if pkg._native.fused_supported(D, O) else 'aggregate + dense'}
     del model, table, csr, out_rows
     torch.cuda.empty_cache()
