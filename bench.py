@@ -216,6 +216,7 @@ def main():
 
     if rank == 0:
         result.update(kernel_breakdown(pkg, model, graph, args.steps, shape, args.shape, args.layers, D, O))
+        result['train'] = guarded(lambda: train_breakdown(pkg, model, graph, shape, D, O))
     if not args.no_eval:                                    # every rank takes part (collectives when W > 1)
         if rank != 0:                                       # the sharded pass needs ONE graph on all ranks: rank 0's
             del model, graph
@@ -674,6 +675,51 @@ def kernel_breakdown(pkg, model, graph, K, shape, shape_name, n_layers, D, O):
     except (OSError, KeyError, ValueError) as err:
         roof['traffic_note'] = 'no PMC traffic file: %s' % err
     return {'roofline': roof, 'kernels': kern}
+
+
+def train_breakdown(pkg, model, graph, shape, D, O):
+    """the aggregation backward (autograd through model.py:99-101, 111-118; main.py:66) on its own kernels, timed
+    with HIP events on the launch stream: mgcn_aggregate_bwd = agg_bwd_gee (per-slot gradient of the per-edge table, streamed),
+    agg_bwd_gx (+ hub pre-pass; by-source sums through the mirror map) and the by-type reduction for the relation table, for
+    both layer widths of the benchmark; plus the training-mode forward aggregation (mgcn_aggregate_fwd, what `.train()` runs).
+    Algorithmic bytes, every distinct byte once: g [N, 2D] + x [N, D] + per-edge table [2E, D] read, gx [N, D] + gee [2E, D]
+    written, 16-byte records + mirror + slot_dst per slot: 16 N D + 16 E D + 48 E."""
+    nat = pkg._native
+    N, R, E = shape['N'], shape['R'], shape['E']
+    dev = model.entity_embedding.device
+    csr = graph.csr(2 * R + 1)
+    if not csr.has_backward:
+        return {'error': 'graph prepared without the backward indices'}
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for name, d in (('layer1_D%d' % D, D), ('layer2_D%d' % O, O)):
+        x = (torch.randn(N, d, generator=g) * 0.3).to(dev)
+        rel = (torch.randn(2 * R + 1, d, generator=g) * 0.5).to(dev)
+        ee = (torch.randn(2 * E, d, generator=g) * 0.5).to(dev)
+        grad = (torch.randn(N, 3 * d, generator=g) * 0.1).to(dev)
+        agg = torch.empty((N, 3 * d), device=dev)
+        le = torch.ones(d, device=dev)
+        K = 20
+        res = {}
+        for what, fn, nbytes in (
+                ('aggregate_bwd', lambda: nat.aggregate_bwd(csr, x, rel, ee, grad), 16 * N * d + 16 * E * d + 48 * E),
+                ('aggregate_fwd_train', lambda: nat.aggregate_fwd(csr, x, rel, ee, True, le, agg), agg_kernel_bytes(N, 2 * E, 2 * R, d))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(K):
+                fn()
+            c.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(c) * 1e3 / K
+            res[what] = {'us': us, 'algorithmic_bytes': nbytes, 'GBps': nbytes / us / 1e3, 'hbm_frac': nbytes / us / 1e3 / HBM_PEAK_GBS}
+        out[name] = res
+        del x, rel, ee, grad, agg
+    out['note'] = ('device time of the launches of one call (events on the launch stream, %d calls back to back: caches warm); '
+                   'aggregate_bwd = gee + gx (+ hub pre-pass) + relation-table reduction, no float atomics' % K)
+    return out
 
 
 def scale_tables(model):
