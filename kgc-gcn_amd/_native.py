@@ -308,12 +308,8 @@ FUSED_TUNE = int(os.environ.get('MGCN_FUSED_TUNE', '0'), 0)
 
 
 def tune_generation(tune=None):
-    """Packing code of the kernel generation a `tune` word forces (0 = the shape's own; generation 5 carries its stage-width
-    variant, tune bits 4-7, in bits 8-11: mgcn_pack_weights_gen)."""
-    t = FUSED_TUNE if tune is None else int(tune)
-    if t & 0x4000:
-        return 5 | (((t >> 4) & 15) << 8)
-    f = (t >> 10) & 3
+    """Kernel generation a `tune` word forces (0 = the shape's own)."""
+    f = ((FUSED_TUNE if tune is None else int(tune)) >> 10) & 3
     return 0 if f == 0 else (4 if f == 1 else f)
 
 

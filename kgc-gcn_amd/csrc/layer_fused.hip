@@ -22,17 +22,15 @@ namespace {
 bool lockstep_shape(int32_t dim_in, int32_t dim_out) { return dim_in <= 256 && mgcn::fused2_takes(dim_in, dim_out); }
 int pack_generation(int32_t dim_in, int32_t dim_out) { return lockstep_shape(dim_in, dim_out) ? 2 : 3; }
 bool generation_takes(int gen, int32_t dim_in, int32_t dim_out) {
-  if (gen == 5) return mgcn::fused5_takes(dim_in, dim_out);
   if (gen == 4) return mgcn::fused4_takes(dim_in, dim_out);
   if (gen == 2) return lockstep_shape(dim_in, dim_out);
   return gen == 3 && mgcn::fused3_takes(dim_in, dim_out);
 }
 }  // namespace
 
-// generation: 0 = the shape's own; 2 / 3 / 4 / 5; for generation 5 bits 8-11 carry its stage-width variant (layer_fused5.hip)
+// generation: 0 = the shape's own; 2 / 3 / 4
 extern "C" size_t mgcn_packed_weights_bytes_gen(int32_t generation, int32_t dim_in, int32_t dim_out) {
-  const int gen = (generation & 255) ? (generation & 255) : pack_generation(dim_in, dim_out);
-  if (gen == 5) return mgcn::fused5_packed_bytes(dim_in, dim_out, (generation >> 8) & 15);
+  const int gen = generation ? generation : pack_generation(dim_in, dim_out);
   if (gen == 4) return mgcn::fused4_packed_bytes(dim_in, dim_out);
   if (gen == 2) return mgcn::fused2_packed_bytes(dim_in, dim_out);
   return mgcn::fused3_packed_bytes(dim_in, dim_out);
@@ -45,12 +43,11 @@ extern "C" size_t mgcn_packed_weights_bytes(int32_t dim_in, int32_t dim_out) {
 extern "C" int mgcn_pack_weights_gen(int32_t generation, int32_t dim_in, int32_t dim_out, const float *w_dev, float *wp_dev,
                                      size_t wp_bytes, void *stream) {
   MGCN_REQUIRE(dim_in > 0 && dim_out > 0 && w_dev && wp_dev, "pack_weights: bad arguments");
-  const int gen = (generation & 255) ? (generation & 255) : pack_generation(dim_in, dim_out);
-  MGCN_REQUIRE(gen >= 2 && gen <= 5 && generation_takes(gen, dim_in, dim_out),
+  const int gen = generation ? generation : pack_generation(dim_in, dim_out);
+  MGCN_REQUIRE(gen >= 2 && gen <= 4 && generation_takes(gen, dim_in, dim_out),
                "pack_weights: generation %d does not take D=%d O=%d", gen, dim_in, dim_out);
-  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes_gen(generation ? generation : gen, dim_in, dim_out) && mgcn::aligned16(wp_dev),
+  MGCN_REQUIRE(wp_bytes >= mgcn_packed_weights_bytes_gen(gen, dim_in, dim_out) && mgcn::aligned16(wp_dev),
                "pack_weights: packed buffer too small or misaligned");
-  if (gen == 5) return mgcn::fused5_pack(dim_in, dim_out, (generation >> 8) & 15, w_dev, wp_dev, stream);
   if (gen == 4) return mgcn::fused4_pack(dim_in, dim_out, w_dev, wp_dev, stream);
   if (gen == 2) return mgcn::fused2_pack(dim_in, dim_out, w_dev, wp_dev, stream);
   return mgcn::fused3_pack(dim_in, dim_out, w_dev, wp_dev, stream);
@@ -115,7 +112,7 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
   }
   // tune bits 10-11: 0 = the launch's own kernel; 1 / 2 / 3 force generation 4 / 2 / 3 (A/B runs; wp_dev must be packed for it:
   // mgcn_pack_weights_gen; generations 2 and 3 share one packing for O > 128)
-  const int forced = (tune & 0x4000) ? 5 : (((tune >> 10) & 3) == 1 ? 4 : ((tune >> 10) & 3));   // bit 14: generation 5
+  const int forced = ((tune >> 10) & 3) == 1 ? 4 : ((tune >> 10) & 3);
   const int gen = forced == 0 ? mgcn_fused_kernel_generation(dim_in, dim_out, node_end - node_begin, num_row_bounds > 0) : forced;
   MGCN_REQUIRE(forced != 3 || !lockstep_shape(dim_in, dim_out) || dim_out > 128,
                "layer_fwd_fused: tune %d: generation 3 reads another packing than generation 2 for O <= 128", tune);
@@ -123,12 +120,6 @@ extern "C" int mgcn_layer_fwd_fused(int64_t num_nodes, int64_t num_edges_half, i
                dim_in, dim_out);
   MGCN_REQUIRE(num_row_bounds >= 0 && num_row_bounds <= 4096 && (num_row_bounds == 0 || row_bounds_dev),
                "layer_fwd_fused: bad row bounds");
-  if (gen == 5)
-    return mgcn::fused5_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
-                               loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,
-                               bn_beta_dev, bn_eps, out_dev, ldo, node_begin, node_end, ee_sub_in, ee_sub_out,
-                               num_chunks > 0 ? hubinfo_dev : nullptr, chunk_begin, partial_dev,
-                               want_rel ? rels_weight_dev : nullptr, want_rel ? rel_out_dev : nullptr, tune, stream);
   if (gen == 4)
     return mgcn::fused4_launch(num_nodes, dim_in, dim_out, num_rel_rows, rowptr_dev, rec_dev, x_dev, ldx, rel_dev,
                                loop_rel_dev, ee_dev, loop_edge_dev, wp_dev, bias_dev, bn_mean_dev, bn_var_dev, bn_gamma_dev,

@@ -75,18 +75,6 @@ int fused4_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
                   const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, const int32_t *row_bounds_dev,
                   int32_t num_row_bounds, int32_t tune, void *stream);
 
-// fused layer, fifth generation (layer_fused5.hip): D <= 256, O <= 208; the lockstep roles on balanced stages of the concatenated K axis
-bool fused5_takes(int32_t dim_in, int32_t dim_out);
-size_t fused5_packed_bytes(int32_t dim_in, int32_t dim_out, int32_t variant);
-int fused5_pack(int32_t dim_in, int32_t dim_out, int32_t variant, const float *w_dev, void *wp_dev, void *stream);
-int fused5_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t num_rel_rows, const int32_t *rowptr_dev,
-                  const mgcn_edge_rec *rec_dev, const float *x_dev, int64_t ldx, const float *rel_dev,
-                  const float *loop_rel_dev, const float *ee_dev, const float *loop_edge_dev, const void *wp_dev,
-                  const float *bias_dev, const float *bn_mean_dev, const float *bn_var_dev, const float *bn_gamma_dev,
-                  const float *bn_beta_dev, float bn_eps, float *out_dev, int64_t ldo, int64_t node_begin,
-                  int64_t node_end, int64_t ee_sub_in, int64_t ee_sub_out, const int32_t *hubinfo_dev, int64_t chunk_begin,
-                  const float *partial_dev, const float *rels_weight_dev, float *rel_out_dev, int32_t tune, void *stream);
-
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace mgcn
