@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # exact-f32 MFMA: what the algorithmic flops of the dense step cost in f32
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA: what the kernel's six split products are issued on
 KERNEL_SOURCES = ('layer_fused2.hip', 'layer_fused3.hip', 'layer_fused.hip', 'aggregate.hip')
-TRAFFIC_FILE = 'r03_traffic.json'
+TRAFFIC_FILE = 'r04_traffic.json'
 
 
 def synth_graph(shape, seed=0, zipf=0.0):

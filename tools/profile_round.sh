@@ -1,12 +1,12 @@
 #!/bin/bash
-# Profiles of bench.py for round $1 (default r03; run on the GPU box from the repo root): rocprofv3 --kernel-trace --stats of the bench
+# Profiles of bench.py for round $1 (default r04; run on the GPU box from the repo root): rocprofv3 --kernel-trace --stats of the bench
 # command (2 layers and 1 layer, so the two fused launches can be told apart), the evaluation kernels, and the PMC
 # passes (FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes).
 # Plus the configs[4] slice (one rank's 1/8 of a 2M-entity / 20M-triple / dim-512 layer: layer_fused3_kernel) under the
 # same tracer. Results land under gpurun_out/prof_<round>/; tools/profile_round_summary.py turns them into profiles/<round>_*.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 B="--steps 100 --warmup 10 --no-cpu-baseline --no-eval --no-fb --no-scale"

@@ -31,7 +31,7 @@ def counter_per_dispatch(d, kernel_substr):
 
 def main():
     out = sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+    rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
     prof = os.path.join(ROOT, 'profiles')
     traffic_only = '--traffic-only' in sys.argv     # (the PMC passes run first, so that the traced bench lines can quote the file)
     for tag, name in () if traffic_only else (('trace_l2', 'wn18rr_2layer'), ('trace_l1', 'wn18rr_1layer'), ('trace_fb', 'fb15k237'), ('trace_eval', 'eval'),
