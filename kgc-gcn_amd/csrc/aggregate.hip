@@ -601,6 +601,89 @@ __global__ __launch_bounds__(256) void agg_bwd_grel_partial_kernel(BwdArgs p, in
   }
 }
 
+// Stage 1 of the by-type reduction AND the per-edge gradient in one pass over the slots in type order (the training step asks
+// for both; a third of the backward's bytes are saved: g and x rows are gathered once instead of twice). One lane group per chunk
+// of kTypeChunk entries of typeslots, U slots per batch: slot ids, then records + destinations, then the 3 U rows, all in
+// flight together (the unfused stage 1 walked its 16 slots as 16 chains of three dependent round trips). Per slot
+// P = (g[dst, half] * norm) * x[src]; gee[slot] = P * rel[type] (agg_bwd_gee_kernel's value, bit for bit) and the chunk's partial
+// sum takes P * ee[slot] in entry order (agg_bwd_grel_partial_kernel's sum, bit for bit).
+template <int VEC, int CPL>
+__global__ __launch_bounds__(256) void agg_bwd_gee_grel_kernel(BwdArgs p, int gs_log2) {
+  using V = Vec<VEC>;
+  using T = typename V::type;
+  constexpr int U = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);
+  const int gs = 1 << gs_log2;
+  const int lig = threadIdx.x & (gs - 1);
+  const int64_t chunk = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> gs_log2;
+  if (chunk >= p.nchunks_type) return;
+  const int nchunk = p.d / VEC;
+  const int64_t e2 = 2 * int64_t(p.e);
+  const int64_t lo = chunk * kTypeChunk;
+  const int64_t hi = (lo + kTypeChunk < e2) ? lo + kTypeChunk : e2;
+  T acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = V::zero();
+  int cur_type = p.rec[p.typeslots[lo]].y;
+  int64_t out_row = (p.typeptr[cur_type] == lo) ? int64_t(p.nchunks_type) + cur_type : chunk;
+  for (int64_t i = lo; i < hi; i += U) {
+    int slot[U], sd[U];
+    int4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) slot[u] = p.typeslots[(i + u < hi) ? i + u : hi - 1];   // (clamped: no branch around a load)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r[u] = p.rec[slot[u]];
+      sd[u] = p.slot_dst[slot[u]];
+    }
+    T gv[U][CPL], xv[U][CPL], ev[U][CPL], rv[U][CPL];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float *gr = p.g + int64_t(sd[u] & 0x7fffffff) * p.ldg + ((sd[u] >> 31) & 1) * p.d;
+      const float *xr = p.x + int64_t(r[u].x) * p.ldx;
+      const float *er = p.ee + int64_t(slot[u]) * p.d;
+      const float *rr = p.rel + int64_t(r[u].y) * p.d;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int ch = (lig + c * gs < nchunk) ? lig + c * gs : nchunk - 1;   // (clamped: lanes past the row store nothing)
+        gv[u][c] = V::load(gr + ch * VEC);
+        xv[u][c] = V::load(xr + ch * VEC);
+        ev[u][c] = V::load(er + ch * VEC);
+        rv[u][c] = V::load(rr + ch * VEC);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i + u < hi) {
+        if (r[u].y != cur_type) {  // uniform across the group: a new type inside the chunk starts at typeptr[type]
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int ch = lig + c * gs;
+            if (ch < nchunk) V::store(p.ws + out_row * p.d + ch * VEC, acc[c]);
+            acc[c] = V::zero();
+          }
+          cur_type = r[u].y;
+          out_row = int64_t(p.nchunks_type) + cur_type;
+        }
+        const float w = __int_as_float(r[u].z);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int ch = lig + c * gs;
+          if (ch < nchunk) {
+            const T pm = V::mul(V::muls(gv[u][c], w), xv[u][c]);
+            V::store(p.gee + int64_t(slot[u]) * p.d + ch * VEC, V::mul(pm, rv[u][c]));
+            acc[c] = V::add(acc[c], V::mul(pm, ev[u][c]));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = lig + c * gs;
+    if (ch < nchunk) V::store(p.ws + out_row * p.d + ch * VEC, acc[c]);
+  }
+}
+
 // Stage 2: grel[t] = partial[nchunks + t] + partial[c] for every chunk boundary strictly inside t's range. One
 // workgroup per relation row: lane group j adds the chunk rows j, j + J, j + 2J, ... of the range in that order (four
 // loads in flight), then group 0 adds the head row and the J group sums in group order — a fixed summation tree.
@@ -932,7 +1015,9 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
   p.rel_rows = num_rel_rows;
   p.nchunks_type = int32_t((2 * num_edges_half + kTypeChunk - 1) / kTypeChunk);
   p.hub_ws = workspace_dev ? workspace_dev + (int64_t(p.nchunks_type) + num_rel_rows) * dim : nullptr;
-  if (gee_dev && num_edges_half > 0) {
+  // gee and grel together (the training step): one pass over the slots in type order instead of two (LAB_NOTES.md, round 4)
+  const bool fused_gee_grel = gee_dev && grel_dev && ee_dev && num_edges_half > 0;
+  if (gee_dev && num_edges_half > 0 && !fused_gee_grel) {
     MGCN_LAUNCH_GEOM(agg_bwd_gee_kernel, p, 2 * num_edges_half, g, stream);
     MGCN_CHECK_LAUNCH("agg_bwd_gee_kernel");
   }
@@ -952,7 +1037,11 @@ extern "C" int mgcn_aggregate_bwd(int64_t num_nodes, int64_t num_edges_half, int
   }
   if (grel_dev) {
     if (p.nchunks_type > 0) {
-      MGCN_LAUNCH_GEOM(agg_bwd_grel_partial_kernel, p, p.nchunks_type, g, stream);
+      if (fused_gee_grel) {
+        MGCN_LAUNCH_GEOM(agg_bwd_gee_grel_kernel, p, p.nchunks_type, g, stream);
+      } else {
+        MGCN_LAUNCH_GEOM(agg_bwd_grel_partial_kernel, p, p.nchunks_type, g, stream);
+      }
       MGCN_CHECK_LAUNCH("agg_bwd_grel_partial_kernel");
     }
     {

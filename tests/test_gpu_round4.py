@@ -197,3 +197,26 @@ def test_score_backward_at_full_entity_count(pkg):
     for got, want, name in ((x.grad, x64.grad, 'x'), (ent.grad, e64.grad, 'ent'), (bias.grad, b64.grad, 'bias')):
         scale = float(want.abs().max())
         assert float((got.double() - want).abs().max()) <= 2e-5 * scale + 1e-12, name
+
+
+@pytest.mark.parametrize('D', [100, 200, 36])
+def test_fused_gee_grel_backward_equals_the_two_kernels(pkg, oracle, D):
+    """mgcn_aggregate_bwd asked for gee AND grel runs one pass over the slots in type order (agg_bwd_gee_grel_kernel); asked for
+    one of them it runs the round-1 kernels. Same per-slot arithmetic, same summation order: the gradients are the same bits
+    (autograd of model.py:99-101, 111-118 w.r.t. the per-edge and relation tables)."""
+    N, R, E = 3000, 9, 40000
+    tri = oracle.synthetic_triples(N, R, E, seed=8, zipf=1.1)
+    ei, ea = oracle.build_edge_list(tri, R)
+    csr = pkg.GraphCSR(N, 2 * R + 1, torch.from_numpy(ei), torch.from_numpy(ea)[0], torch.device(DEV))
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(N, D, generator=g).to(DEV)
+    rel = torch.randn(2 * R + 1, D, generator=g).to(DEV)
+    ee = torch.randn(2 * E, D, generator=g).to(DEV)
+    grad = torch.randn(N, 2 * D, generator=g).to(DEV)
+    nat = pkg._native
+    gx, gee, grel = nat.aggregate_bwd(csr, x, rel, ee, grad)
+    _, gee1, none = nat.aggregate_bwd(csr, x, rel, ee, grad, want_gx=False, want_grel=False)
+    _, none2, grel1 = nat.aggregate_bwd(csr, x, rel, ee, grad, want_gx=False, want_gee=False)
+    assert none is None and none2 is None
+    assert torch.equal(gee, gee1) and torch.equal(grel, grel1)
+    assert torch.isfinite(gx).all() and float(gee.abs().mean()) > 0 and float(grel.abs().mean()) > 0
