@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void agg_bwd_grel_final_kernel(BwdArgs p, int 
   using V = Vec<VEC>;
   using T = typename V::type;
   extern __shared__ float red[];  // [J][D]
-  constexpr int U = 4;
+  constexpr int U = 16 / CPL > 0 ? 16 / CPL : 1;   // rows in flight per lane group (one workgroup per relation row: few workgroups,
+                                                   // each a chain of round trips — WN18RR: 22 of them with ~490 chunk rows each)
   const int gs = 1 << gs_log2, groups = 256 >> gs_log2;
   const int grp = threadIdx.x >> gs_log2, lig = threadIdx.x & (gs - 1);
   const int64_t t = blockIdx.x;
