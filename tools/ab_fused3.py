@@ -98,8 +98,11 @@ def main():
                 r['us'] = round(1e3 * a.elapsed_time(b) / K, 2)
                 if os.environ.get('AB_COLD'):     # as in the real step: the other layer's 120-200 MB pass through the caches in between
                     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+                    keep_input = bool(os.environ.get('AB_COLD_KEEP_INPUT'))   # as in the real step: the layer input was just written
                     for e0, e1 in evs:
                         cold_dst.copy_(cold_src)
+                        if keep_input:
+                            x.add_(0.0)                                          # (read + rewrite: resident again, like a fresh layer output)
                         e0.record()
                         run()
                         e1.record()
