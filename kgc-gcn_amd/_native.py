@@ -127,7 +127,10 @@ def _same_device(*ts):
 
 
 # ------------------------------------------------------------------------------------------------
-HUB_THRESHOLD = int(os.environ.get('MGCN_HUB_THRESHOLD', '64'))   # slots per (half, destination) above which it is a hub
+# slots per (half, destination) above which it is a hub. 32: below a gather group's fair share of an FB15k-237 tile (~42 slots per
+# half and stage), so that no single row outlasts its stage; measured on that shape's step: 64 -> 0.323, 48 -> 0.311, 32 -> 0.303, 24 -> 0.314,
+# 16 -> 0.331 ms (tools/hub_sweep.sh). WN18RR / uniform graphs have no such rows either way.
+HUB_THRESHOLD = int(os.environ.get('MGCN_HUB_THRESHOLD', '32'))
 HUB_CHUNK = int(os.environ.get('MGCN_HUB_CHUNK', '64'))             # slots per hub chunk
 
 
