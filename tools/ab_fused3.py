@@ -120,6 +120,10 @@ def main():
                                      'multiply(total,ring+phase waits,-,-,convert,conv_wait,mfma,other)': [round(float(d[:, :8, i].mean()), 1) for i in range(8)],
                                      'gather(total,ring_wait,load_wait,kbatches,issue,prefetch_next,consume,other)': [round(float(d[:, 8:, i].mean()), 1) for i in range(8)],
                                      'gather_total_max': round(float(d[:, 8:, 0].max()), 1), 'multiply_total_max': round(float(d[:, :8, 0].max()), 1)}
+                        if os.environ.get('AB_DUMP_WG'):       # per-workgroup totals (kcycles): gather waves' mean / slowest, load wait
+                            r['diag']['per_wg_gather_mean'] = [round(float(v), 1) for v in d[:, 8:, 0].mean(1)]
+                            r['diag']['per_wg_gather_max'] = [round(float(v), 1) for v in d[:, 8:, 0].max(1)]
+                            r['diag']['per_wg_load_wait'] = [round(float(v), 1) for v in d[:, 8:, 2].mean(1)]
                 entry['tunes'][hex(tune)] = r
         res['layers'].append(entry)
         x, rel = ref, rel_ref
