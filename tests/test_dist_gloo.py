@@ -106,3 +106,50 @@ def test_shard_bounds_and_filter_index(pkg):
     f = pkg.dist.FilterIndex.from_known({(3, 1): [5, 2], (0, 0): [7]}, 4)
     assert f.keys.tolist() == [0, 13] and f.ptr.tolist() == [0, 1, 3] and f.tails.tolist() == [7, 2, 5]
     assert f.query_keys(torch.tensor([3]), torch.tensor([1])).tolist() == [13]
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    pkg = load_pkg()
+    d = pkg.dist
+    t = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 10 * rank
+    out = d._gather(t, None, world)                                        # [world * 3, 2] in rank order
+    empty = d._gather(t[:0], None, world)                                  # zero rows on every rank: no collective, no error
+    keys = list(d._INTO_TENSOR)                                            # the capability was probed exactly once
+    ints = d._gather(torch.tensor([rank, rank + 7]), None, world)
+    # a rank-local failure of the collective must RAISE, not make this rank take another collective than its peers are in
+    # (ADVICE r3): all ranks pass a wrongly sized output here, so the error is the same everywhere and nobody is left waiting
+    raised = False
+    try:
+        d._gather_into(torch.empty((world * 3 + 1, 2)), t, None)
+    except Exception:                                                      # noqa: BLE001 (torch raises RuntimeError / ValueError)
+        raised = True
+    q.put((rank, out.clone(), tuple(empty.shape), keys, ints.clone(), raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_helper_gloo():
+    """dist._gather_into: one collective in rank order; the all_gather_into_tensor capability is decided once per backend by a
+    probe every rank runs, zero rows are no collective, and a failing collective raises on the rank it fails on."""
+    world = 2
+    port = 29500 + (os.getpid() + 991) % 2000
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, rest) for r, *rest in [q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = torch.cat([torch.arange(6, dtype=torch.float32).reshape(3, 2) + 10 * r for r in range(world)])
+    for r in range(world):
+        out, empty_shape, keys, ints, raised = got[r]
+        assert torch.equal(out, want)
+        assert empty_shape == (0, 2)
+        assert keys == [('gloo', 'cpu')]
+        assert ints.tolist() == [0, 7, 1, 8]
+        assert raised
