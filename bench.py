@@ -777,6 +777,11 @@ def eval_wallclock(pkg, model, graph, params, shape, dev, edge_index, edge_attr,
             torch.cuda.synchronize()
             out[name] = time.perf_counter() - t0
         out[name.replace('_s', '_mrr')] = res['mrr']
+    parts = {}                              # where the default evaluation's time goes (one more run, a synchronisation per part)
+    model._enc_cache = None
+    pkg.dist.evaluate_sharded(model, graph, queries, filt, parts=parts)
+    out['parts_s'] = {k: round(v, 6) for k, v in parts.items()}
+    out['in_scope_share'] = round((parts.get('encoder_s', 0.0) + parts.get('kernels_s', 0.0)) / max(sum(parts.values()), 1e-12), 4)
     if rank == 0:
         batches = []
         for i in range(0, 2 * n_eval, B):
