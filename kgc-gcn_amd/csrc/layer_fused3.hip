@@ -745,7 +745,10 @@ struct Shape3 {
 };
 Shape3 shape3(int d, int nch = 0) {   // nch: float4 per lane and slot walk (0 = by width)
   Shape3 s;
-  s.nch = nch ? nch : ((d > 128 && d <= 256) ? 2 : 1);   // wider inputs: 128-column passes leave room for 80-row tiles
+  // 128-column passes by default (one float4 per lane, four slots per batch): round 4's A/B on the product build has the 200-wide
+  // layer at 96 / 107 us (warm / cold) against 108 / 118 with one 256-column walk (two float4, two slots per batch) on the WN18RR
+  // shape and 187 against 193 on FB15k-237; the 256-column walk stays reachable through `tune` bits 12-13 = 2
+  s.nch = nch ? nch : 1;
   const int wpass = 128 * s.nch;
   s.npass = (d + wpass - 1) / wpass;
   const int wlast = d - wpass * (s.npass - 1);
