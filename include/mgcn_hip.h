@@ -238,7 +238,7 @@ int mgcn_dense_bn_tanh_fwd(int64_t num_nodes, int32_t dim_in, int32_t dim_out, c
  * with the arithmetic of mgcn_matmul_f32's small-matrix kernel (bit-identical results); NULL = not computed.
  * row_bounds_dev (optional; NULL / 0 = equal runs): num_row_bounds + 1 strictly increasing row offsets from node_begin, first 0,
  * last node_end - node_begin: workgroup i takes destinations [b_i, b_i+1) — the caller's work-balanced runs
- * (slots + a constant per row; one run per CU; no run longer than ceil(rows / runs / 80) * 80 rows, which is what the tile
+ * (slots + a constant per row; one run per CU; no run longer than the equal split ceil(rows / runs) rounded up to 16 rows (up to 80) or to 80 rows (past it), which is what the tile
  * height is chosen for), computed once per graph on the host (GraphCSR.workgroup_bounds). Rows do not
  * depend on the runs (fixed k order per row). With bounds given, a generation-2 shape whose tiling would leave the chip short of
  * two tiles per CU takes generation 3 (dim_out > 128); generation 2 itself ignores them. The bounds are read by the launch, not

@@ -870,7 +870,8 @@ int fused3_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   if (row_bounds_dev && num_row_bounds > 0 && nrows > 0) {   // the caller's runs, one workgroup each (at most one per CU is the point)
     p.bounds = row_bounds_dev;
     grid = num_row_bounds;
-    rpw = ((nrows + grid - 1) / grid + 79) / 80 * 80;         // (the longest run the convention allows: whole 80-row tiles)
+    const int64_t per = (nrows + grid - 1) / grid;            // (GraphCSR.workgroup_bounds caps its runs by the same rule)
+    rpw = per <= 80 ? (per + 15) / 16 * 16 : (per + 79) / 80 * 80;
   }
   const int nt = pick_nt3(dim_out);
   const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;

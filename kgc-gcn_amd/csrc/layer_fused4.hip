@@ -742,7 +742,8 @@ int fused4_launch(int64_t num_nodes, int32_t dim_in, int32_t dim_out, int32_t nu
   if (row_bounds_dev && num_row_bounds > 0 && nrows > 0) {   // the caller's runs, one workgroup each
     p.bounds = row_bounds_dev;
     grid = num_row_bounds;
-    rpw = ((nrows + grid - 1) / grid + 79) / 80 * 80;         // (the longest run the convention allows: whole 80-row tiles)
+    const int64_t per = (nrows + grid - 1) / grid;            // (GraphCSR.workgroup_bounds caps its runs by the same rule)
+    rpw = per <= 80 ? (per + 15) / 16 * 16 : (per + 79) / 80 * 80;         // (the longest run the convention allows: whole 80-row tiles)
   }
   const size_t rel_bytes = rel_dev ? size_t(num_rel_rows - 1) * dim_in * 4 : 0;
   const int t_nrt = tune & 15, t_ub = (tune >> 4) & 15, t_rel = (tune >> 8) & 3, t_ph = (tune >> 12) & 3;

@@ -112,8 +112,8 @@ class GraphCSR(object):
         """Row offsets (relative to n0) that cut destinations [n0, n1) into at most `groups` contiguous runs of about
         equal WORK for the elastic fused launch (include/mgcn_hip.h (2b) row_bounds_dev): work(row) = its slots in both
         halves + row_weight (the self-loop message, the row's share of the multiply, the output row; a hub's slots are
-        summed by the pre-pass, so a hub counts as a row without slots). No run is longer than ceil(rows per run / 80)
-        tiles of 80 rows. int32 device tensor [g + 1], strictly increasing from 0 to n1 - n0, or None when the heaviest of the
+        summed by the pre-pass, so a hub counts as a row without slots). No run is longer than the equal split rounded up to whole
+        16-row tiles (at most 80 rows: one tile) or, past that, to whole 80-row tiles. int32 device tensor [g + 1], strictly increasing from 0 to n1 - n0, or None when the heaviest of the
         EQUAL runs carries less than `min_gain` times the mean work (nothing to gain); cached per (range, groups)."""
         n0, n1, groups = int(n0), int(n1), int(groups)
         key = ('wg', n0, n1, groups, int(row_weight), float(min_gain))
@@ -137,7 +137,8 @@ class GraphCSR(object):
             cuts = torch.cummax(cuts, 0).values if g > 1 else cuts
             # no run longer than the whole tiles an equal split would take (80-row tiles: a run one row longer costs a
             # whole extra tile — its own pass over the weights): forward and backward clamps, feasible since g * cap >= n
-            cap = (-(-n // g) + 79) // 80 * 80
+            per = -(-n // g)
+            cap = (per + 15) // 16 * 16 if per <= 80 else (per + 79) // 80 * 80      # (the launch sizes its tiles by the same rule)
             b = [0] + cuts.tolist() + [n]
             for i in range(1, g):
                 b[i] = min(max(b[i], b[i - 1] + 1), b[i - 1] + cap)
